@@ -1,0 +1,73 @@
+"""ctypes loader of the C-ABI library (include/g4s_rasterizer.h).
+
+There is deliberately NO fallback: if libg4s_hip.so is missing or fails to load, importing the
+operators raises.  The product path never routes through the CPU oracle or any torch emulation."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libg4s_hip.so")
+
+RESIZE_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+
+class G4sLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_size_t) for n in (
+        "rec", "clamped", "depth_sorted", "tiles_touched", "geom_bytes", "entries", "binning_bytes", "ranges",
+        "final_T", "n_contrib", "image_bytes")]
+
+
+# symbol -> (restype, argtypes); tests/test_abi.py checks this table against include/g4s_rasterizer.h
+SIGNATURES = {
+    "g4s_last_error": (ctypes.c_char_p, []),
+    "g4s_version": (ctypes.c_char_p, []),
+    "g4s_rasterizer_forward": (c_i, [RESIZE_FN, c_p, RESIZE_FN, c_p, RESIZE_FN, c_p, c_i, c_i, c_i, c_p, c_i, c_i,
+                                     c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p,
+                                     c_p, c_i, c_p]),
+    "g4s_rasterizer_backward_workspace": (c_sz, [c_i, c_i]),
+    "g4s_rasterizer_backward": (c_i, [c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p,
+                                      c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      c_p, c_p, c_p, c_sz, c_i, c_p]),
+    "g4s_rasterizer_mark_visible": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p]),
+    "g4s_knn_workspace": (c_sz, [c_i]),
+    "g4s_knn_mean_dist": (c_i, [c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "g4s_rasterizer_layout": (c_i, [c_i, c_i, c_i, c_i, ctypes.POINTER(G4sLayout)]),
+    "g4s_profile_enable": (None, [c_i]),
+    "g4s_profile_kernels": (c_i, []),
+    "g4s_profile_name": (ctypes.c_char_p, [c_i]),
+    "g4s_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
+    "g4s_profile_reset": (None, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libg4s_hip.so and bind every exported symbol.  Raises RuntimeError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It must be the one
+    # already resident when libg4s_hip.so is mapped, otherwise two runtimes end up in the process
+    # and torch's stream / memory handles are meaningless to ours.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m g4splat_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().g4s_last_error().decode()

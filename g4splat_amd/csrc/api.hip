@@ -1,0 +1,384 @@
+// extern "C" entry points of libg4s_hip.so (see include/g4s_rasterizer.h) and the host-side
+// sequencing of the kernels.  Mirrors Rasterizer::forward / ::backward / ::markVisible
+// (dsr/cuda_rasterizer/rasterizer_impl.cu:141-153,198-448) and SimpleKNN::knn
+// (knn/simple_knn.cu:185-221).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "g4s_internal.h"
+
+using namespace g4s;
+
+extern "C" int g4s_knn_launch_internal(int P, const float* points, float* meanDists, char* workspace, hipStream_t s);
+
+namespace {
+
+thread_local char t_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// One pinned word per host thread for the num_rendered read-back.
+uint32_t* pinned_word() {
+    thread_local uint32_t* p = nullptr;
+    if (!p) {
+        if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+    }
+    return p;
+}
+
+inline bool trace_on() {
+    static const bool on = getenv("G4S_TRACE") != nullptr;
+    return on;
+}
+inline bool misaligned(const void* p, size_t a) { return p != nullptr && ((size_t)p % a) != 0; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(G4S_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// CHECK_CUDA of the reference (auxiliary.h:295-302): launch errors always, sync + check in debug.
+// G4S_TRACE=1 in the environment: synchronise after every stage and log it to stderr.
+#define CHECK_LAUNCH(what)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = hipGetLastError();                                                          \
+        if (_e == hipSuccess && (debug || trace_on())) _e = hipStreamSynchronize(stream);           \
+        if (trace_on()) { fprintf(stderr, "[g4s] %s: %s\n", what, hipGetErrorString(_e)); fflush(stderr); } \
+        if (_e != hipSuccess) return fail(G4S_ERR_HIP, "%s: %s", what, hipGetErrorString(_e));      \
+    } while (0)
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
+enum ProfId { PF_PREPROCESS_FWD, PF_DEPTH_SORT, PF_COUNT_SCAN, PF_EMIT, PF_TILE_SORT, PF_TILE_RANGES, PF_BLEND_FWD,
+              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_COUNT };
+const char* const kProfNames[PF_COUNT] = {"preprocess_fwd", "depth_sort", "count_scan", "emit", "tile_sort",
+                                          "tile_ranges",    "blend_fwd",  "blend_bwd",  "preprocess_bwd"};
+struct ProfRec { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_prof_on) {
+        if (on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+        else on = false;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(ProfRec{id, a, b});
+    }
+};
+
+uint32_t higher_msb(uint32_t n) {  // rasterizer_impl.cu:35-50
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+}  // namespace
+
+extern "C" const char* g4s_last_error(void) { return t_err; }
+
+extern "C" void g4s_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+extern "C" int g4s_profile_kernels(void) { return PF_COUNT; }
+extern "C" const char* g4s_profile_name(int id) { return (id >= 0 && id < PF_COUNT) ? kProfNames[id] : ""; }
+// Sum of the recorded durations of kernel group `id` (ms) and the number of recordings.
+// Synchronises on the recorded events.  g4s_profile_reset() drops all recordings.
+extern "C" int g4s_profile_read(int id, double* total_ms, int* count) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0; int n = 0;
+    for (const ProfRec& r : g_prof) {
+        if (r.id != id) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return G4S_ERR_HIP;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return G4S_ERR_HIP;
+        tot += ms; n++;
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    return G4S_OK;
+}
+extern "C" void g4s_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (const ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+}
+extern "C" const char* g4s_version(void) { return "g4s-hip 0.1.0 gfx950"; }
+
+extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out) {
+    if (!out || P < 0 || R < 0 || width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "bad layout query");
+    const int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    const GeomLayout g = geom_layout((size_t)P);
+    const BinLayout b = bin_layout((size_t)R);
+    const ImgLayout im = img_layout((size_t)width * height, (size_t)tiles);
+    // which ping-pong half holds the results is fixed by the (even / data-independent) pass counts
+    const int tile_bits = (int)higher_msb((uint32_t)tiles);
+    const int passes = (tile_bits + 7) / 8;
+    out->rec = g.rec;
+    out->clamped = g.clamped;
+    out->depth_sorted = g.vals_a;  // four passes -> back in the first buffer
+    out->tiles_touched = g.tiles_touched;
+    out->geom_bytes = g.bytes;
+    out->entries = (passes & 1) ? b.ent_b : b.ent_a;
+    out->binning_bytes = b.bytes;
+    out->ranges = im.ranges;
+    out->final_T = im.final_T;
+    out->n_contrib = im.n_contrib;
+    out->image_bytes = im.bytes;
+    return G4S_OK;
+}
+
+extern "C" int g4s_rasterizer_forward(
+    g4s_resize_fn geometry_buffer, void* geometry_ctx, g4s_resize_fn binning_buffer, void* binning_ctx,
+    g4s_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+    float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+    float* out_others, int* radii, int debug, void* stream_) {
+    (void)tan_fovx; (void)tan_fovy; (void)prefiltered;
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0 || width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P, width, height must be positive");
+    if (!geometry_buffer || !binning_buffer || !image_buffer)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "resize callbacks must not be NULL");
+    if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_others)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    const int tiles_x = (width + TILE - 1) / TILE, tiles_y = (height + TILE - 1) / TILE;
+    const int tiles = tiles_x * tiles_y;
+    if (tiles > 65536) return fail(G4S_ERR_INVALID_ARGUMENT, "image too large: %d tiles > 65536", tiles);
+    const size_t N = (size_t)width * height;
+
+    // image chunk first: with P == 0 the frame is still background (rasterize_points.cu:85-99
+    // returns zero-filled outputs in that case; the binding handles P == 0 itself)
+    const ImgLayout IL = img_layout(N, (size_t)tiles);
+    char* img = image_buffer(image_ctx, IL.bytes);
+    if (!img) return fail(G4S_ERR_ALLOC, "image buffer callback returned NULL");
+    img = align_ptr(img);
+    uint32_t* ranges = (uint32_t*)(img + IL.ranges);
+    float* final_T = (float*)(img + IL.final_T);
+    uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
+    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, stream));  // rasterizer_impl.cu:311
+
+    int R = 0;
+    const float* rec_ptr = nullptr;
+    const uint64_t* entries_ptr = nullptr;
+    if (P > 0) {
+        if (!means3D || !opacities) return fail(G4S_ERR_INVALID_ARGUMENT, "means3D / opacities must not be NULL");
+        if (!shs && !colors_precomp)  // NUM_CHANNELS == 3 here; mirrors rasterizer_impl.cu:243-246
+            return fail(G4S_ERR_UNSUPPORTED, "provide SHs or precomputed colours");
+        if (!transMat_precomp && (!scales || !rotations))
+            return fail(G4S_ERR_INVALID_ARGUMENT, "provide scales+rotations or transMat_precomp");
+        if (misaligned(rotations, 16) || misaligned(scales, 8))
+            return fail(G4S_ERR_INVALID_ARGUMENT, "rotations must be 16-byte and scales 8-byte aligned");
+        if (shs && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+            return fail(G4S_ERR_INVALID_ARGUMENT, "SH degree %d does not fit M = %d coefficients", D, M);
+
+        const GeomLayout GL = geom_layout((size_t)P);
+        char* geom = geometry_buffer(geometry_ctx, GL.bytes);
+        if (!geom) return fail(G4S_ERR_ALLOC, "geometry buffer callback returned NULL");
+        geom = align_ptr(geom);
+        float* rec = (float*)(geom + GL.rec);
+        uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
+        uint32_t* keys_a = (uint32_t*)(geom + GL.keys_a);
+        uint32_t* keys_b = (uint32_t*)(geom + GL.keys_b);
+        uint32_t* vals_a = (uint32_t*)(geom + GL.vals_a);
+        uint32_t* vals_b = (uint32_t*)(geom + GL.vals_b);
+        uint32_t* block_sums = (uint32_t*)(geom + GL.block_sums);
+        uint32_t* block_offs = (uint32_t*)(geom + GL.block_offs);
+        uint32_t* d_total = (uint32_t*)(geom + GL.total);
+        if (radii == nullptr) radii = (int*)(geom + GL.internal_radii);  // rasterizer_impl.cu:230-233
+
+        PreprocessArgs pa{};
+        pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.tiles_x = tiles_x; pa.tiles_y = tiles_y;
+        pa.means3D = means3D; pa.scales = scales; pa.rotations = rotations; pa.opacities = opacities; pa.shs = shs;
+        pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp;
+        pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.cam_pos = cam_pos;
+        pa.scale_modifier = scale_modifier;
+        pa.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16));
+        pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
+        pa.depth_keys = keys_a; pa.gidx = vals_a;
+        { ProfScope ps(PF_PREPROCESS_FWD, stream); launch_preprocess_fwd(pa, stream); }
+        CHECK_LAUNCH("preprocess_fwd");
+
+        // depth order of the Gaussians (stable => ties by ascending index)
+        int cur;
+        { ProfScope ps(PF_DEPTH_SORT, stream);
+          cur = radix_sort_u32_pairs(keys_a, keys_b, vals_a, vals_b, P, (uint32_t*)(geom + GL.hist),
+                                     (uint32_t*)(geom + GL.bin_total), GL.nchunks, stream); }
+        CHECK_LAUNCH("depth sort");
+        const uint32_t* gidx_sorted = cur ? vals_b : vals_a;
+
+        { ProfScope ps(PF_COUNT_SCAN, stream);
+          launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, d_total, GL.nblocks, stream); }
+        CHECK_LAUNCH("count scan");
+
+        // the one host synchronisation of the forward (rasterizer_impl.cu:281-282)
+        uint32_t* h_total = pinned_word();
+        if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
+        HIP_TRY(hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (*h_total > 0x7FFFFFFFu) return fail(G4S_ERR_INVALID_ARGUMENT, "num_rendered overflows int");
+        R = (int)*h_total;
+
+        const BinLayout BL = bin_layout((size_t)R);
+        char* bin = binning_buffer(binning_ctx, BL.bytes);
+        if (!bin) return fail(G4S_ERR_ALLOC, "binning buffer callback returned NULL");
+        bin = align_ptr(bin);
+        uint64_t* ent_a = (uint64_t*)(bin + BL.ent_a);
+        uint64_t* ent_b = (uint64_t*)(bin + BL.ent_b);
+        entries_ptr = ent_a;
+        if (R > 0) {
+            { ProfScope ps(PF_EMIT, stream);
+              launch_emit(P, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, GL.nblocks,
+                          stream); }
+            CHECK_LAUNCH("emit");
+            const int tile_bits = (int)higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:301
+            int c2;
+            { ProfScope ps(PF_TILE_SORT, stream);
+              c2 = radix_sort_u64_keys(ent_a, ent_b, R, ENTRY_TILE_SHIFT, ENTRY_TILE_SHIFT + tile_bits,
+                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total), BL.nchunks, stream); }
+            CHECK_LAUNCH("tile partition");
+            entries_ptr = c2 ? ent_b : ent_a;
+            { ProfScope ps(PF_TILE_RANGES, stream); launch_tile_ranges(R, entries_ptr, ranges, stream); }
+            CHECK_LAUNCH("tile ranges");
+        }
+        rec_ptr = rec;
+    } else {
+        // keep the callback protocol: zero-sized chunks are still requested
+        (void)geometry_buffer(geometry_ctx, 0);
+        (void)binning_buffer(binning_ctx, 0);
+    }
+
+    BlendFwdArgs ba{};
+    ba.W = width; ba.H = height; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y;
+    ba.ranges = ranges; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
+    ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
+    if (getenv("G4S_SKIP_BLEND")) return R;  // bring-up aid: leave the binning state for inspection
+    { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
+    CHECK_LAUNCH("blend_fwd");
+    return R;
+}
+
+extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
+    (void)P;
+    return align_up((size_t)(R > 0 ? R : 1) * GRAD_FLOATS * 4) + 256;
+}
+
+extern "C" int g4s_rasterizer_backward(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+    const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    char* workspace, size_t workspace_bytes, int debug, void* stream_) {
+    (void)scale_modifier;
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (P == 0) return G4S_OK;  // rasterize_points.cu:197: nothing to do, outputs are [0,*]
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "state buffers must not be NULL");
+    if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
+        !dL_dtransMat || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
+    if (workspace_bytes < g4s_rasterizer_backward_workspace(P, R) || !workspace)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    if (misaligned(rotations, 16) || misaligned(scales, 8) || misaligned(dL_drot, 16) || misaligned(dL_dscale, 8))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "rotations/dL_drot must be 16-byte, scales/dL_dscale 8-byte aligned");
+
+    const int tiles_x = (width + TILE - 1) / TILE, tiles_y = (height + TILE - 1) / TILE;
+    const int tiles = tiles_x * tiles_y;
+    const GeomLayout GL = geom_layout((size_t)P);
+    const BinLayout BL = bin_layout((size_t)R);
+    const ImgLayout IL = img_layout((size_t)width * height, (size_t)tiles);
+    char* geom = align_ptr(geom_buffer);
+    char* img = align_ptr(image_buffer);
+    const float* rec = (const float*)(geom + GL.rec);
+    if (radii == nullptr) radii = (const int*)(geom + GL.internal_radii);
+    float* grad_inst = (float*)align_ptr(workspace);
+
+    if (R > 0) {
+        char* bin = align_ptr(binning_buffer);
+        const int tile_bits = (int)higher_msb((uint32_t)tiles);
+        const int passes = (tile_bits + 7) / 8;
+        BlendBwdArgs bb{};
+        bb.W = width; bb.H = height; bb.tiles_x = tiles_x; bb.tiles_y = tiles_y;
+        bb.ranges = (const uint32_t*)(img + IL.ranges);
+        bb.entries = (const uint64_t*)(bin + ((passes & 1) ? BL.ent_b : BL.ent_a));
+        bb.rec = rec; bb.bg = background;
+        bb.final_T = (const float*)(img + IL.final_T);
+        bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
+        bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst;
+        { ProfScope ps(PF_BLEND_BWD, stream); launch_blend_bwd(bb, stream); }
+        CHECK_LAUNCH("blend_bwd");
+    }
+
+    // backward.cu:618-619: W,H re-derived through float truncation (may be W-1 / H-1)
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    PreprocessBwdArgs pb{};
+    pb.P = P; pb.D = D; pb.M = M;
+    pb.W = (int)(focal_x * tan_fovx * 2);
+    pb.H = (int)(focal_y * tan_fovy * 2);
+    pb.means3D = means3D; pb.scales = scales; pb.rotations = rotations; pb.shs = shs;
+    pb.transMat_precomp = transMat_precomp; pb.colors_precomp = colors_precomp;
+    pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
+    pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
+    pb.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
+    pb.dL_dmean3D = dL_dmean3D; pb.dL_dtransMat = dL_dtransMat; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
+    pb.dL_drot = dL_drot;
+    { ProfScope ps(PF_PREPROCESS_BWD, stream); launch_preprocess_bwd(pb, stream); }
+    CHECK_LAUNCH("preprocess_bwd");
+    return G4S_OK;
+}
+
+extern "C" int g4s_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                                           const float* projmatrix, uint8_t* present, void* stream_) {
+    (void)projmatrix;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (P < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P < 0");
+    if (P == 0) return G4S_OK;
+    if (!means3D || !viewmatrix || !present) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
+    launch_mark_visible(P, means3D, viewmatrix, present, stream);
+    CHECK_LAUNCH("mark_visible");
+    return G4S_OK;
+}
+
+extern "C" int g4s_knn_mean_dist(int P, const float* points, float* meanDists, char* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (P < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P < 0");
+    if (P == 0) return G4S_OK;
+    if (!points || !meanDists || !workspace) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
+    if (workspace_bytes < g4s_knn_workspace(P)) return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    g4s_knn_launch_internal(P, points, meanDists, workspace, stream);
+    CHECK_LAUNCH("knn");
+    return G4S_OK;
+}

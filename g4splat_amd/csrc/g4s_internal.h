@@ -1,0 +1,164 @@
+// Internal declarations shared by the translation units of libg4s_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/g4s_rasterizer.h"
+
+namespace g4s {
+
+constexpr int TILE = 16;           // tile edge in pixels (part of the output definition, auxiliary.h:66-76)
+constexpr int REC_FLOATS = 20;     // per-Gaussian splat record, 80 B = 5 x float4
+constexpr int GRAD_FLOATS = 18;    // per-instance gradient record (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
+constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
+constexpr int SORT_CHUNK = 2048;   // keys per wave-private radix chunk
+// Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
+// <= 65536), 31..0 Gaussian index.  Every field sits on a natural 16/32-bit boundary on purpose:
+// hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load and then drops the mask.
+constexpr int ENTRY_TILE_SHIFT = 48;
+constexpr int ENTRY_K_SHIFT = 32;
+__host__ __device__ inline uint32_t entry_idx(uint64_t e) { return (uint32_t)e; }
+__host__ __device__ inline uint32_t entry_k(uint64_t e) { return (uint32_t)(e >> ENTRY_K_SHIFT) & 0xFFFFu; }
+__host__ __device__ inline uint32_t entry_tile(uint64_t e) { return (uint32_t)(e >> ENTRY_TILE_SHIFT); }
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Sub-allocation of the three caller-owned chunks.  Private between forward and backward
+// (the reference's GeometryState/BinningState/ImageState, rasterizer_impl.h:21-73).
+struct GeomLayout {
+    size_t rec, clamped, tiles_touched, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
+        block_sums, block_offs, total, bytes;
+    int nchunks;   // radix chunks over P
+    int nblocks;   // 256-wide blocks over P
+};
+struct BinLayout {
+    size_t ent_a, ent_b, hist, bin_total, bytes;
+    int nchunks;
+};
+struct ImgLayout {
+    size_t ranges, final_T, n_contrib, bytes;
+};
+
+inline GeomLayout geom_layout(size_t P) {
+    GeomLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    L.nchunks = (int)((P + SORT_CHUNK - 1) / SORT_CHUNK);
+    L.nblocks = (int)((P + 255) / 256);
+    L.rec = take(P * REC_FLOATS * 4);
+    L.clamped = take(P);
+    L.tiles_touched = take(P * 4);
+    L.internal_radii = take(P * 4);
+    L.keys_a = take(P * 4);
+    L.keys_b = take(P * 4);
+    L.vals_a = take(P * 4);
+    L.vals_b = take(P * 4);
+    L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
+    L.bin_total = take(256 * 4);
+    L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.total = take(256);
+    L.bytes = o + 256;  // slack for aligning the chunk base
+    return L;
+}
+inline BinLayout bin_layout(size_t R) {
+    BinLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    L.nchunks = (int)((R + SORT_CHUNK - 1) / SORT_CHUNK);
+    L.ent_a = take((R ? R : 1) * 8);
+    L.ent_b = take((R ? R : 1) * 8);
+    L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
+    L.bin_total = take(256 * 4);
+    L.bytes = o + 256;
+    return L;
+}
+inline ImgLayout img_layout(size_t N, size_t tiles) {
+    ImgLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
+    L.ranges = take(tiles * 8);
+    L.final_T = take(N * 3 * 4);
+    L.n_contrib = take(N * 2 * 4);
+    L.bytes = o + 256;
+    return L;
+}
+inline char* align_ptr(char* p) { return (char*)align_up((size_t)p); }
+
+// ---- launchers (each defined next to its kernels) --------------------------------------
+
+struct PreprocessArgs {
+    int P, D, M, W, H, tiles_x, tiles_y;
+    const float *means3D, *scales, *rotations, *opacities, *shs, *transMat_precomp, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *cam_pos;
+    float scale_modifier;
+    bool sh_vec16;  // shs is [P,16,3] on a 16-byte aligned base
+    float* rec;
+    uint8_t* clamped;
+    uint32_t* tiles_touched;
+    int* radii;
+    uint32_t* depth_keys;
+    uint32_t* gidx;
+};
+void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+
+// Stable LSD radix sort.  32-bit keys with 32-bit payload (ping-pong a<->b, result index
+// returned: 0 = in *_a, 1 = in *_b) over bits [0,32).
+int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
+                         uint32_t* hist, uint32_t* bin_total, int nchunks, hipStream_t s);
+// 64-bit keys-only over bits [begin_bit, end_bit).
+int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
+                        uint32_t* bin_total, int nchunks, hipStream_t s);
+
+// Exclusive scan (in depth order) of tiles_touched; total written to *total (device).
+void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
+                       uint32_t* block_offs, uint32_t* total, int nblocks, hipStream_t s);
+void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,
+                 const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
+                 hipStream_t s);
+void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s);
+
+struct BlendFwdArgs {
+    int W, H, tiles_x, tiles_y;
+    const uint32_t* ranges;
+    const uint64_t* entries;
+    const float* rec;
+    const float* bg;
+    float* final_T;
+    uint32_t* n_contrib;
+    float* out_color;
+    float* out_others;
+};
+void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
+
+struct BlendBwdArgs {
+    int W, H, tiles_x, tiles_y;
+    const uint32_t* ranges;
+    const uint64_t* entries;
+    const float* rec;
+    const float* bg;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    const float* dL_depths;
+    float* grad_inst;  // R x GRAD_FLOATS
+};
+void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
+
+struct PreprocessBwdArgs {
+    int P, D, M, W, H;  // W,H: the truncated values of backward.cu:618-619
+    const float *means3D, *scales, *rotations, *shs, *transMat_precomp, *colors_precomp;
+    const float *viewmatrix, *projmatrix, *campos;
+    const int* radii;
+    const float* rec;
+    const uint8_t* clamped;
+    const float* grad_inst;
+    bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
+    float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
+        *dL_drot;
+};
+void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+
+}  // namespace g4s

@@ -1,0 +1,508 @@
+// Per-Gaussian kernels: forward preprocess (K1), near-plane visibility (K9) and the
+// per-Gaussian backward (K8).  One thread per Gaussian, streaming; HBM-bound.
+//
+// Reference semantics: dsr/cuda_rasterizer/forward.cu:20-253, backward.cu:20-139,443-641,
+// auxiliary.h.  The arithmetic order is the reference's (glm products expanded in glm's
+// summation order), compiled with -ffp-contract=off.
+#include "g4s_internal.h"
+#include "g4s_device.h"
+
+namespace g4s {
+
+__constant__ float c_SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                 -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float c_SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                 0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                 -0.5900435899266435f};
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+// forward.cu:75-115 -- T = transpose(splat2world) * world2ndc * ndc2pix, rows Tu,Tv,Tw.
+__device__ __forceinline__ void compute_transmat(F3 p, float sx, float sy, float mod, const float* R,
+                                                 const float* proj, int W, int H, float* T) {
+    const float s0 = mod * sx, s1 = mod * sy;
+    const float Mrow[3][4] = {{R[0] * s0, R[1] * s0, R[2] * s0, 0.0f},
+                              {R[3] * s1, R[4] * s1, R[5] * s1, 0.0f},
+                              {p.x, p.y, p.z, 1.0f}};
+    const float hw = (float)((float)W / 2.0), cw = (float)((float)(W - 1) / 2.0);
+    const float hh = (float)((float)H / 2.0), ch = (float)((float)(H - 1) / 2.0);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        float c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            c[j] = Mrow[r][0] * proj[j] + Mrow[r][1] * proj[4 + j] + Mrow[r][2] * proj[8 + j] +
+                   Mrow[r][3] * proj[12 + j];
+        T[0 * 3 + r] = c[0] * hw + c[3] * cw;
+        T[1 * 3 + r] = c[1] * hh + c[3] * ch;
+        T[2 * 3 + r] = c[3];
+    }
+}
+
+// forward.cu:119-147
+__device__ __forceinline__ bool compute_aabb(const float* T, float cutoff, float& px, float& py, float& ex,
+                                             float& ey) {
+    const float* T0 = T;
+    const float* T1 = T + 3;
+    const float* T3 = T + 6;
+    const float t0 = cutoff * cutoff, t1 = cutoff * cutoff, t2 = -1.0f;
+    const float distance = (T3[0] * T3[0] * t0 + T3[1] * T3[1] * t1) + T3[2] * T3[2] * t2;
+    const float inv = 1 / distance;
+    const float f0 = inv * t0, f1 = inv * t1, f2 = inv * t2;
+    if (distance == 0.0f) return false;
+    px = (f0 * T0[0] * T3[0] + f1 * T0[1] * T3[1]) + f2 * T0[2] * T3[2];
+    py = (f0 * T1[0] * T3[0] + f1 * T1[1] * T3[1]) + f2 * T1[2] * T3[2];
+    const float tmp0 = (f0 * T0[0] * T0[0] + f1 * T0[1] * T0[1]) + f2 * T0[2] * T0[2];
+    const float tmp1 = (f0 * T1[0] * T1[0] + f1 * T1[1] * T1[1]) + f2 * T1[2] * T1[2];
+    const float h0 = px * px - tmp0, h1 = py * py - tmp1;
+    ex = sqrtf(fmaxf(1e-4f, h0));
+    ey = sqrtf(fmaxf(1e-4f, h1));
+    return true;
+}
+
+// Loads the 3*(deg+1)^2 active SH floats of Gaussian idx into registers.  vec16: the records are
+// 192 B ([16][3] floats) on a 16-byte aligned base, so they are fetched as 16-byte quads.
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int deg, bool vec16,
+                                        float* sh /*48*/) {
+    const int n = 3 * (deg + 1) * (deg + 1);
+    if (vec16) {
+        const float4* p = reinterpret_cast<const float4*>(shs + idx * 48);
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            if (4 * q < n) {
+                const float4 v = p[q];
+                sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+            }
+        }
+    } else {
+        const float* p = shs + idx * (size_t)M * 3;
+#pragma unroll
+        for (int i = 0; i < 48; i++)
+            if (i < n) sh[i] = p[i];
+    }
+}
+
+// forward.cu:20-71.  sh = this Gaussian's active coefficients in registers (load_sh).
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, F3 pos, F3 campos, float* rgb,
+                                          uint32_t& clamp_bits) {
+    const float dx = pos.x - campos.x, dy = pos.y - campos.y, dz = pos.z - campos.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) r[c] = SH_C0 * sh[c];
+    if (deg > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            r[c] = r[c] - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                r[c] = r[c] + c_SH_C2[0] * xy * sh[12 + c] + c_SH_C2[1] * yz * sh[15 + c] +
+                       c_SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] + c_SH_C2[3] * xz * sh[21 + c] +
+                       c_SH_C2[4] * (xx - yy) * sh[24 + c];
+            if (deg > 2) {
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    r[c] = r[c] + c_SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + c_SH_C3[1] * xy * z * sh[30 + c] +
+                           c_SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] +
+                           c_SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                           c_SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] +
+                           c_SH_C3[5] * z * (xx - yy) * sh[42 + c] + c_SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
+            }
+        }
+    }
+    clamp_bits = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        r[c] += 0.5f;
+        if (r[c] < 0) clamp_bits |= (1u << c);
+        rgb[c] = fmaxf(r[c], 0.0f);
+    }
+}
+
+// K1: forward.cu:150-253.  Also seeds the depth sort (key = depth bits, CULLED_KEY if the
+// Gaussian emits nothing; payload = index).
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (idx >= a.P) return;
+    int radius_out = 0;
+    uint32_t touched = 0, key = CULLED_KEY, clamp_bits = 0;
+    float rec[REC_FLOATS];
+#pragma unroll
+    for (int i = 0; i < REC_FLOATS; i++) rec[i] = 0.0f;
+
+    const F3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+    const F3 p_view = xform_point_4x3(p, a.viewmatrix);
+    if (p_view.z > 0.2f) {  // in_frustum, auxiliary.h:184-209
+        float T[9];
+        F3 normal;
+        if (a.transMat_precomp == nullptr) {
+            float R[9];
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+            quat_to_rotmat(q, R);
+            compute_transmat(p, sc.x, sc.y, a.scale_modifier, R, a.projmatrix, a.W, a.H, T);
+            normal = xform_vec_4x3(mk3(R[6], R[7], R[8]), a.viewmatrix);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; i++) T[i] = a.transMat_precomp[9 * (size_t)idx + i];
+            normal = mk3(0.0f, 0.0f, 1.0f);
+        }
+        // T is kept even if the Gaussian is culled below (forward.cu:197-200)
+#pragma unroll
+        for (int i = 0; i < 9; i++) rec[8 + i] = T[i];
+        const float cosv = -((p_view.x * normal.x + p_view.y * normal.y) + p_view.z * normal.z);
+        if (cosv != 0) {
+            const float mult = cosv > 0 ? 1.0f : -1.0f;
+            normal = mk3(mult * normal.x, mult * normal.y, mult * normal.z);
+            float cx, cy, ex, ey;
+            if (compute_aabb(T, 3.0f, cx, cy, ex, ey)) {
+                const float radius = ceilf(fmaxf(ex, ey));
+                int x0, y0, x1, y1;
+                get_rect(cx, cy, sat_int(radius), a.tiles_x, a.tiles_y, x0, y0, x1, y1);
+                const int area = (x1 - x0) * (y1 - y0);
+                if (area != 0) {
+                    float rgb[3];
+                    if (a.colors_precomp == nullptr) {
+                        float sh[48];
+                        load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+                        sh_to_rgb(a.D, sh, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), rgb, clamp_bits);
+                    } else {
+                        rgb[0] = a.colors_precomp[3 * (size_t)idx];
+                        rgb[1] = a.colors_precomp[3 * (size_t)idx + 1];
+                        rgb[2] = a.colors_precomp[3 * (size_t)idx + 2];
+                    }
+                    radius_out = sat_int(radius);
+                    touched = (uint32_t)area;
+                    key = __float_as_uint(p_view.z);
+                    rec[0] = cx;
+                    rec[1] = cy;
+                    rec[3] = __uint_as_float(touched);
+                    rec[4] = normal.x;
+                    rec[5] = normal.y;
+                    rec[6] = normal.z;
+                    rec[7] = a.opacities[idx];
+                    rec[17] = rgb[0];
+                    rec[18] = rgb[1];
+                    rec[19] = rgb[2];
+                }
+            }
+        }
+    }
+    float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * 5;
+#pragma unroll
+    for (int i = 0; i < 5; i++) out[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+    a.clamped[idx] = (uint8_t)clamp_bits;
+    a.tiles_touched[idx] = touched;
+    a.radii[idx] = radius_out;
+    a.depth_keys[idx] = key;
+    a.gidx[idx] = (uint32_t)idx;
+}
+
+void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+// K9: rasterizer_impl.cu:54-66
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view,
+                                    uint8_t* __restrict__ present) {
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (idx >= P) return;
+    const F3 p = mk3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    present[idx] = xform_point_4x3(p, view).z > 0.2f ? 1 : 0;
+}
+void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}
+
+// ---- backward ----------------------------------------------------------------------------
+
+// auxiliary.h:237-281, v_R column-major
+__device__ __forceinline__ float4 quat_to_rotmat_vjp(const float4 q, const float* v_R) {
+    const float s = 1.0f / sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+#define VR(c, r) v_R[(c) * 3 + (r)]
+    float4 v;
+    v.x = 2.f * (x * (VR(1, 2) - VR(2, 1)) + y * (VR(2, 0) - VR(0, 2)) + z * (VR(0, 1) - VR(1, 0)));
+    v.y = 2.f * (-2.f * x * (VR(1, 1) + VR(2, 2)) + y * (VR(0, 1) + VR(1, 0)) + z * (VR(0, 2) + VR(2, 0)) +
+                 w * (VR(1, 2) - VR(2, 1)));
+    v.z = 2.f * (x * (VR(0, 1) + VR(1, 0)) - 2.f * y * (VR(0, 0) + VR(2, 2)) + z * (VR(1, 2) + VR(2, 1)) +
+                 w * (VR(2, 0) - VR(0, 2)));
+    v.w = 2.f * (x * (VR(0, 2) + VR(2, 0)) + y * (VR(1, 2) + VR(2, 1)) - 2.f * z * (VR(0, 0) + VR(1, 1)) +
+                 w * (VR(0, 1) - VR(1, 0)));
+#undef VR
+    return v;
+}
+
+// auxiliary.h:130-140
+__device__ __forceinline__ F3 dnormvdv(F3 v, F3 dv) {
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    return mk3(((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32,
+               (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32,
+               (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32);
+}
+
+// backward.cu:20-139.  Writes all M coefficients of dL_dsh (zeros above the active degree)
+// and returns the view-direction term to add to dL_dmean.
+__device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 pos, F3 campos, uint32_t clamp_bits,
+                                          const float* dL_dcolor, float* __restrict__ dsh, bool vec16) {
+    const F3 dir_orig = mk3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
+    const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    float dRGB[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[c] * ((clamp_bits >> c) & 1u ? 0.0f : 1.0f);
+    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+    float coef[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) coef[i] = 0.0f;
+    coef[0] = SH_C0;
+    if (deg > 0) {
+        coef[1] = -SH_C1 * y;
+        coef[2] = SH_C1 * z;
+        coef[3] = -SH_C1 * x;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            dx[c] = -SH_C1 * sh[9 + c];
+            dy[c] = -SH_C1 * sh[3 + c];
+            dz[c] = SH_C1 * sh[6 + c];
+        }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            coef[4] = c_SH_C2[0] * xy;
+            coef[5] = c_SH_C2[1] * yz;
+            coef[6] = c_SH_C2[2] * (2.f * zz - xx - yy);
+            coef[7] = c_SH_C2[3] * xz;
+            coef[8] = c_SH_C2[4] * (xx - yy);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dx[c] += c_SH_C2[0] * y * sh[12 + c] + c_SH_C2[2] * 2.f * -x * sh[18 + c] + c_SH_C2[3] * z * sh[21 + c] +
+                         c_SH_C2[4] * 2.f * x * sh[24 + c];
+                dy[c] += c_SH_C2[0] * x * sh[12 + c] + c_SH_C2[1] * z * sh[15 + c] + c_SH_C2[2] * 2.f * -y * sh[18 + c] +
+                         c_SH_C2[4] * 2.f * -y * sh[24 + c];
+                dz[c] += c_SH_C2[1] * y * sh[15 + c] + c_SH_C2[2] * 2.f * 2.f * z * sh[18 + c] + c_SH_C2[3] * x * sh[21 + c];
+            }
+            if (deg > 2) {
+                coef[9] = c_SH_C3[0] * y * (3.f * xx - yy);
+                coef[10] = c_SH_C3[1] * xy * z;
+                coef[11] = c_SH_C3[2] * y * (4.f * zz - xx - yy);
+                coef[12] = c_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                coef[13] = c_SH_C3[4] * x * (4.f * zz - xx - yy);
+                coef[14] = c_SH_C3[5] * z * (xx - yy);
+                coef[15] = c_SH_C3[6] * x * (xx - 3.f * yy);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dx[c] += (c_SH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + c_SH_C3[1] * sh[30 + c] * yz +
+                              c_SH_C3[2] * sh[33 + c] * -2.f * xy + c_SH_C3[3] * sh[36 + c] * -3.f * 2.f * xz +
+                              c_SH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) + c_SH_C3[5] * sh[42 + c] * 2.f * xz +
+                              c_SH_C3[6] * sh[45 + c] * 3.f * (xx - yy));
+                    dy[c] += (c_SH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + c_SH_C3[1] * sh[30 + c] * xz +
+                              c_SH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) +
+                              c_SH_C3[3] * sh[36 + c] * -3.f * 2.f * yz + c_SH_C3[4] * sh[39 + c] * -2.f * xy +
+                              c_SH_C3[5] * sh[42 + c] * -2.f * yz + c_SH_C3[6] * sh[45 + c] * -3.f * 2.f * xy);
+                    dz[c] += (c_SH_C3[1] * sh[30 + c] * xy + c_SH_C3[2] * sh[33 + c] * 4.f * 2.f * yz +
+                              c_SH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) + c_SH_C3[4] * sh[39 + c] * 4.f * 2.f * xz +
+                              c_SH_C3[5] * sh[42 + c] * (xx - yy));
+                }
+            }
+        }
+    }
+    const int nact = (deg + 1) * (deg + 1);
+    if (vec16) {  // M == 16, 16-byte aligned 192-byte record: twelve 16-byte stores
+        float o[48];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float cf = (i < nact) ? coef[i] : 0.0f;
+            o[3 * i] = cf * dRGB[0]; o[3 * i + 1] = cf * dRGB[1]; o[3 * i + 2] = cf * dRGB[2];
+        }
+        float4* o4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+        for (int q = 0; q < 12; q++) o4[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < M) {
+                const float cf = (i < nact) ? coef[i] : 0.0f;
+                dsh[3 * i + 0] = cf * dRGB[0]; dsh[3 * i + 1] = cf * dRGB[1]; dsh[3 * i + 2] = cf * dRGB[2];
+            }
+        }
+        for (int i = 48; i < M * 3; i++) dsh[i] = 0.0f;
+    }
+    const F3 dL_ddir = mk3(dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
+                           dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
+                           dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2]);
+    return dnormvdv(dir_orig, dL_ddir);
+}
+
+// K8: backward.cu:586-641 + compute_transmat_aabb :443-584.  First folds this Gaussian's
+// per-instance gradient records (written by the blend backward, one per (tile, Gaussian)
+// instance, contiguous at [inst_off, inst_off + count)) in a fixed order -- the
+// deterministic replacement of the reference's float atomics.
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (idx >= a.P) return;
+    float g[GRAD_FLOATS];
+#pragma unroll
+    for (int i = 0; i < GRAD_FLOATS; i++) g[i] = 0.0f;
+    float dmean3[3] = {0, 0, 0}, dscale[2] = {0, 0};
+    float4 drot = make_float4(0, 0, 0, 0);
+    float dmean2[3] = {0, 0, 0};
+    float dT_out[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool visible = a.radii[idx] > 0;
+    float* dsh = a.M > 0 ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr;
+
+    if (visible) {
+        const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)idx * 5;
+        const float4 q0 = rq[0];
+        const uint32_t inst_off = __float_as_uint(q0.z), count = __float_as_uint(q0.w);
+        const float2* gp = reinterpret_cast<const float2*>(a.grad_inst + (size_t)inst_off * GRAD_FLOATS);
+        for (uint32_t k = 0; k < count; k++) {
+#pragma unroll
+            for (int i = 0; i < GRAD_FLOATS / 2; i++) {
+                const float2 v = gp[(size_t)k * (GRAD_FLOATS / 2) + i];
+                g[2 * i] += v.x;
+                g[2 * i + 1] += v.y;
+            }
+        }
+        // g: [0..2] colour, [3..5] normal, [6..14] T (Tu,Tv,Tw), [15..16] mean2D, [17] opacity
+#pragma unroll
+        for (int i = 0; i < 9; i++) dT_out[i] = g[6 + i];
+
+        const bool precomp = (a.scales == nullptr);
+        const float4 q4 = rq[4];
+        const float depth_T8 = q4.x;  // transMats[idx*9+8]
+        float T[9];
+        float Pm[3][4];
+        float R[9];
+        F3 normal = mk3(0, 0, 0), p_orig = mk3(0, 0, 0);
+        float sx = 0, sy = 0;
+        float4 rot = make_float4(1, 0, 0, 0);
+        if (precomp) {
+            const float4 q2 = rq[2], q3 = rq[3];
+            T[0] = q2.x; T[1] = q2.y; T[2] = q2.z; T[3] = q2.w; T[4] = q3.x; T[5] = q3.y; T[6] = q3.z; T[7] = q3.w;
+            T[8] = q4.x;
+        } else {
+            p_orig = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+            rot = reinterpret_cast<const float4*>(a.rotations)[idx];
+            const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+            sx = sc.x;
+            sy = sc.y;
+            quat_to_rotmat(rot, R);
+            const float s0 = 1.0f * sx, s1 = 1.0f * sy;  // scale_modifier ignored (backward.cu:481)
+            const float Mrow[3][4] = {{R[0] * s0, R[1] * s0, R[2] * s0, 0.0f},
+                                      {R[3] * s1, R[4] * s1, R[5] * s1, 0.0f},
+                                      {p_orig.x, p_orig.y, p_orig.z, 1.0f}};
+            const float hw = (float)((float)a.W / 2.0), cw = (float)((float)(a.W - 1) / 2.0);
+            const float hh = (float)((float)a.H / 2.0), ch = (float)((float)(a.H - 1) / 2.0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Pm[0][i] = a.projmatrix[4 * i + 0] * hw + a.projmatrix[4 * i + 3] * cw;
+                Pm[1][i] = a.projmatrix[4 * i + 1] * hh + a.projmatrix[4 * i + 3] * ch;
+                Pm[2][i] = a.projmatrix[4 * i + 3];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    T[c * 3 + r] = Mrow[r][0] * Pm[c][0] + Mrow[r][1] * Pm[c][1] + Mrow[r][2] * Pm[c][2] +
+                                   Mrow[r][3] * Pm[c][3];
+            normal = xform_vec_4x3(mk3(R[6], R[7], R[8]), a.viewmatrix);
+        }
+        float dL_dT[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) dL_dT[i] = g[6 + i];
+        const float mx = g[15], my = g[16];
+        bool early_out = false;
+        if (mx != 0 || my != 0) {  // backward.cu:513-556, low-pass centre path (cutoff-1 formula)
+            const float* T0 = T;
+            const float* T1 = T + 3;
+            const float* T2 = T + 6;
+            const float distance = T2[0] * T2[0] + T2[1] * T2[1] - T2[2] * T2[2];
+            const float f = 1 / (distance);
+            const float dpx_dT00 = f * T2[0], dpx_dT01 = f * T2[1], dpx_dT02 = -f * T2[2];
+            const float dpy_dT10 = f * T2[0], dpy_dT11 = f * T2[1], dpy_dT12 = -f * T2[2];
+            const float dpx_dT30 = T0[0] * (f - 2 * f * f * T2[0] * T2[0]);
+            const float dpx_dT31 = T0[1] * (f - 2 * f * f * T2[1] * T2[1]);
+            const float dpx_dT32 = -T0[2] * (f + 2 * f * f * T2[2] * T2[2]);
+            const float dpy_dT30 = T1[0] * (f - 2 * f * f * T2[0] * T2[0]);
+            const float dpy_dT31 = T1[1] * (f - 2 * f * f * T2[1] * T2[1]);
+            const float dpy_dT32 = -T1[2] * (f + 2 * f * f * T2[2] * T2[2]);
+            dL_dT[0] += mx * dpx_dT00; dL_dT[1] += mx * dpx_dT01; dL_dT[2] += mx * dpx_dT02;
+            dL_dT[3] += my * dpy_dT10; dL_dT[4] += my * dpy_dT11; dL_dT[5] += my * dpy_dT12;
+            dL_dT[6] += mx * dpx_dT30 + my * dpy_dT30;
+            dL_dT[7] += mx * dpx_dT31 + my * dpy_dT31;
+            dL_dT[8] += mx * dpx_dT32 + my * dpy_dT32;
+            if (precomp) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) dT_out[i] = dL_dT[i];
+                early_out = true;
+            }
+        }
+        if (!precomp && !early_out) {
+            float dL_dM[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    dL_dM[c][i] = Pm[0][i] * dL_dT[0 * 3 + c] + Pm[1][i] * dL_dT[1 * 3 + c] + Pm[2][i] * dL_dT[2 * 3 + c];
+            F3 dL_dtn = xform_vec_4x3_T(mk3(g[3], g[4], g[5]), a.viewmatrix);
+            const F3 p_view = xform_point_4x3(p_orig, a.viewmatrix);
+            const float cosv = -((p_view.x * normal.x + p_view.y * normal.y) + p_view.z * normal.z);
+            const float mult = cosv > 0 ? 1.0f : -1.0f;
+            dL_dtn = mk3(mult * dL_dtn.x, mult * dL_dtn.y, mult * dL_dtn.z);
+            const float dL_dRS[9] = {dL_dM[0][0], dL_dM[0][1], dL_dM[0][2], dL_dM[1][0], dL_dM[1][1],
+                                     dL_dM[1][2], dL_dtn.x,    dL_dtn.y,    dL_dtn.z};
+            const float dL_dR[9] = {dL_dRS[0] * sx, dL_dRS[1] * sx, dL_dRS[2] * sx, dL_dRS[3] * sy, dL_dRS[4] * sy,
+                                    dL_dRS[5] * sy, dL_dRS[6],      dL_dRS[7],      dL_dRS[8]};
+            drot = quat_to_rotmat_vjp(rot, dL_dR);
+            dscale[0] = dL_dRS[0] * R[0] + dL_dRS[1] * R[1] + dL_dRS[2] * R[2];
+            dscale[1] = dL_dRS[3] * R[3] + dL_dRS[4] * R[4] + dL_dRS[5] * R[5];
+            dmean3[0] = dL_dM[2][0];
+            dmean3[1] = dL_dM[2][1];
+            dmean3[2] = dL_dM[2][2];
+        }
+        if (a.shs != nullptr) {
+            float sh[48];
+            load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+            const F3 dm = sh_backward(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
+                                      mk3(a.campos[0], a.campos[1], a.campos[2]), a.clamped[idx], g, dsh, a.sh_vec16);
+            dmean3[0] += dm.x;
+            dmean3[1] += dm.y;
+            dmean3[2] += dm.z;
+        }
+        // densification surrogate (backward.cu:637-640): uses the raw blend-accumulated dL_dT
+        // (or, on the precomputed-T path with a centre gradient, the folded one the reference wrote back)
+        dmean2[0] = (float)(dT_out[2] * depth_T8 * 0.5 * (float)a.W);
+        dmean2[1] = (float)(dT_out[5] * depth_T8 * 0.5 * (float)a.H);
+    } else if (dsh != nullptr) {
+        if (a.sh_vec16) {
+            float4* o4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+            for (int q = 0; q < 12; q++) o4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.0f;
+        }
+    }
+
+    a.dL_dmean2D[3 * idx] = dmean2[0]; a.dL_dmean2D[3 * idx + 1] = dmean2[1]; a.dL_dmean2D[3 * idx + 2] = dmean2[2];
+    a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5];
+    a.dL_dopacity[idx] = g[17];
+    a.dL_dcolor[3 * idx] = g[0]; a.dL_dcolor[3 * idx + 1] = g[1]; a.dL_dcolor[3 * idx + 2] = g[2];
+    a.dL_dmean3D[3 * idx] = dmean3[0]; a.dL_dmean3D[3 * idx + 1] = dmean3[1]; a.dL_dmean3D[3 * idx + 2] = dmean3[2];
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.dL_dtransMat[9 * (size_t)idx + i] = dT_out[i];
+    reinterpret_cast<float2*>(a.dL_dscale)[idx] = make_float2(dscale[0], dscale[1]);
+    reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+}
+
+void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace g4s

@@ -1,0 +1,165 @@
+"""`diff_surfel_rasterization._C` for MI355X: the torch <-> raw-pointer glue of the reference
+(dsr/rasterize_points.cu + dsr/ext.cpp:15-19) re-expressed over the C ABI of libg4s_hip.so.
+
+Same three entry points, same argument order, same tuple orders, same error behaviour:
+
+    rasterize_gaussians(...)           -> (num_rendered, color, others, radii, geomBuffer, binningBuffer, imgBuffer)
+                                          dsr/rasterize_points.h:18-38, rasterize_points.cu:39-134
+    rasterize_gaussians_backward(...)  -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat,
+                                           dL_dsh, dL_dscales, dL_drotations)
+                                          dsr/rasterize_points.h:40-63, rasterize_points.cu:136-233
+    mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]      rasterize_points.cu:235-254
+
+torch is plumbing here (device memory, current stream); all compute is in the HIP library.
+There is no CPU path: tensors must live on a HIP device ("cuda" in torch-ROCm).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+NUM_CHANNELS = 3  # dsr/cuda_rasterizer/config.h:15
+
+
+def _check_cuda(t, name):
+    # CHECK_INPUT, rasterize_points.cu:27-28
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def _f32c(t, align=4):
+    """contiguous float32 view whose base address satisfies `align` (clone if a view is offset)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.contiguous()
+    if t.numel() and t.data_ptr() % align:
+        t = t.clone()
+    return t
+
+
+def _ptr(t):
+    # empty tensor => NULL => "absent" (rasterizer_impl.cu:322-323)
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0)
+
+
+class _Scratch:
+    """resizeFunctional (rasterize_points.cu:31-37) as a C callback."""
+
+    def __init__(self, device):
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.error = None
+
+        def _resize(_ctx, nbytes):
+            try:
+                self.tensor.resize_(int(nbytes))
+                return self.tensor.data_ptr() if nbytes else 1  # non-NULL sentinel for empty chunks
+            except Exception as ex:  # surfaced after the C call returns G4S_ERR_ALLOC
+                self.error = ex
+                return 0
+
+        self.cb = _lib.RESIZE_FN(_resize)
+
+
+def _raise(code, what):
+    raise RuntimeError(f"{what} failed ({code}): {_lib.last_error()}")
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, transMat_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("opacity", opacity),
+                    ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos)):
+        _check_cuda(t, name)
+    lib = _lib.load()
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    dev = means3D.device
+    with torch.cuda.device(dev):
+        fopt = dict(dtype=torch.float32, device=dev)
+        geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+        if P == 0:  # rasterize_points.cu:85-99: zero-filled outputs, nothing launched
+            return (0, torch.zeros((NUM_CHANNELS, H, W), **fopt), torch.zeros((7, H, W), **fopt),
+                    torch.zeros((0,), dtype=torch.int32, device=dev), geom.tensor, binning.tensor, img.tensor)
+        out_color = torch.empty((NUM_CHANNELS, H, W), **fopt)
+        out_others = torch.empty((7, H, W), **fopt)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        M = int(sh.size(1)) if sh.size(0) != 0 else 0
+        bg, m3, col, opa = _f32c(background), _f32c(means3D), _f32c(colors), _f32c(opacity)
+        sc, rot, tm = _f32c(scales, 8), _f32c(rotations, 16), _f32c(transMat_precomp)
+        vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh, 16), _f32c(campos)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rendered = lib.g4s_rasterizer_forward(
+            geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(shc),
+            _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp),
+            float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(out_color), _ptr(out_others), _ptr(radii),
+            int(bool(debug)), stream)
+        for s in (geom, binning, img):
+            if s.error is not None:
+                raise s.error
+        if rendered < 0:
+            _raise(rendered, "rasterize_gaussians")
+    return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
+                    ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
+                    ("binningBuffer", binningBuffer), ("imageBuffer", imageBuffer), ("geomBuffer", geomBuffer)):
+        _check_cuda(t, name)
+    lib = _lib.load()
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.size(0) != 0 else 0
+    dev = means3D.device
+    with torch.cuda.device(dev):
+        fopt = dict(dtype=torch.float32, device=dev)
+        make = torch.zeros if P == 0 else torch.empty  # the library writes every element when P > 0
+        dL_dmeans3D = make((P, 3), **fopt)
+        dL_dmeans2D = make((P, 3), **fopt)
+        dL_dcolors = make((P, NUM_CHANNELS), **fopt)
+        dL_dnormal = make((P, 3), **fopt)
+        dL_dopacity = make((P, 1), **fopt)
+        dL_dtransMat = make((P, 9), **fopt)
+        dL_dsh = make((P, M, 3), **fopt)
+        dL_dscales = make((P, 2), **fopt)
+        dL_drotations = make((P, 4), **fopt)
+        if P != 0:
+            ws_bytes = lib.g4s_rasterizer_backward_workspace(P, int(R))
+            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
+            sc, rot, tm = _f32c(scales, 8), _f32c(rotations, 16), _f32c(transMat_precomp)
+            vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh, 16), _f32c(campos)
+            gc, go = _f32c(dL_dout_color), _f32c(dL_dout_others)
+            rad = radii.contiguous()
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = lib.g4s_rasterizer_backward(
+                P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc),
+                float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx),
+                float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
+                _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                _ptr(workspace), ws_bytes, int(bool(debug)), stream)
+            if rc != 0:
+                _raise(rc, "rasterize_gaussians_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    lib = _lib.load()
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        _check_cuda(means3D, "means3D")
+        with torch.cuda.device(means3D.device):
+            m3, vm, pm = _f32c(means3D), _f32c(viewmatrix), _f32c(projmatrix)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(means3D.device).cuda_stream)
+            rc = lib.g4s_rasterizer_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), _ptr(present), stream)
+            if rc != 0:
+                _raise(rc, "mark_visible")
+    return present

@@ -1,0 +1,127 @@
+"""Drop-in replacement of the `diff_surfel_rasterization` Python package on MI355X.
+
+Public surface (names, argument order, defaults, return values and exceptions) follows
+dsr/diff_surfel_rasterization/__init__.py of the reference:
+
+    GaussianRasterizationSettings   NamedTuple, 12 fields in the reference's order   (:158-170)
+    GaussianRasterizer              nn.Module with .markVisible() and .forward()     (:172-222)
+    rasterize_gaussians(...)        functional form                                  (:21-42)
+
+The autograd node calls `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` with the
+reference's argument tuples (:60-80, :109-130) and returns gradients in input order
+(:144-154).  `_C` here is the ctypes front-end of the HIP library (./_C.py), not a pybind module.
+"""
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """Host copy of an argument tuple, taken before a debug-mode launch can corrupt it (:17-19)."""
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_guarded(fn, args, debug, dump_name, banner):
+    """debug=True: on failure dump the CPU snapshot of the arguments and re-raise (:83-90, :133-140)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_name)
+        print(banner)
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        fwd_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                    rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
+            _C.rasterize_gaussians, fwd_args, rs.debug, "snapshot_fw.dump",
+            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        bwd_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh,
+                    rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _call_guarded(
+            _C.rasterize_gaussians_backward, bwd_args, rs.debug, "snapshot_bw.dump",
+            "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        # one gradient per forward input, in input order; raster_settings gets None
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """bool[P]: Gaussians in front of the near plane of this camera (no gradient)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        def absent():  # empty tensor == "not given" for the native side
+            return torch.empty(0, dtype=torch.float32, device=means3D.device)
+
+        shs = absent() if shs is None else shs
+        colors_precomp = absent() if colors_precomp is None else colors_precomp
+        scales = absent() if scales is None else scales
+        rotations = absent() if rotations is None else rotations
+        cov3D_precomp = absent() if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   rs)

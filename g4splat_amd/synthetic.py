@@ -138,24 +138,28 @@ def _face_frames():
 
 
 def _rotmat_to_quat(Rm):
-    """Rotation matrices [n,3,3] -> quaternions (w,x,y,z), numerically safe branch per row."""
-    n = Rm.shape[0]
+    """Rotation matrices [n,3,3] -> quaternions (w,x,y,z); vectorised Shepperd branches."""
+    m = Rm
+    n = m.shape[0]
     q = np.zeros((n, 4))
-    tr = Rm[:, 0, 0] + Rm[:, 1, 1] + Rm[:, 2, 2]
-    for i in range(n):
-        m = Rm[i]
-        if tr[i] > 0:
-            s = math.sqrt(tr[i] + 1.0) * 2
-            q[i] = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
-        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
-            s = math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
-            q[i] = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
-        elif m[1, 1] > m[2, 2]:
-            s = math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
-            q[i] = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
-        else:
-            s = math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
-            q[i] = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+    tr = m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]
+    c0 = tr > 0
+    c1 = ~c0 & (m[:, 0, 0] > m[:, 1, 1]) & (m[:, 0, 0] > m[:, 2, 2])
+    c2 = ~c0 & ~c1 & (m[:, 1, 1] > m[:, 2, 2])
+    c3 = ~c0 & ~c1 & ~c2
+    with np.errstate(invalid="ignore"):
+        s = np.sqrt(np.maximum(tr + 1.0, 1e-30)) * 2
+        q[c0] = np.stack([0.25 * s, (m[:, 2, 1] - m[:, 1, 2]) / s, (m[:, 0, 2] - m[:, 2, 0]) / s,
+                          (m[:, 1, 0] - m[:, 0, 1]) / s], 1)[c0]
+        s = np.sqrt(np.maximum(1.0 + m[:, 0, 0] - m[:, 1, 1] - m[:, 2, 2], 1e-30)) * 2
+        q[c1] = np.stack([(m[:, 2, 1] - m[:, 1, 2]) / s, 0.25 * s, (m[:, 0, 1] + m[:, 1, 0]) / s,
+                          (m[:, 0, 2] + m[:, 2, 0]) / s], 1)[c1]
+        s = np.sqrt(np.maximum(1.0 + m[:, 1, 1] - m[:, 0, 0] - m[:, 2, 2], 1e-30)) * 2
+        q[c2] = np.stack([(m[:, 0, 2] - m[:, 2, 0]) / s, (m[:, 0, 1] + m[:, 1, 0]) / s, 0.25 * s,
+                          (m[:, 1, 2] + m[:, 2, 1]) / s], 1)[c2]
+        s = np.sqrt(np.maximum(1.0 + m[:, 2, 2] - m[:, 0, 0] - m[:, 1, 1], 1e-30)) * 2
+        q[c3] = np.stack([(m[:, 1, 0] - m[:, 0, 1]) / s, (m[:, 0, 2] + m[:, 2, 0]) / s, (m[:, 1, 2] + m[:, 2, 1]) / s,
+                          0.25 * s], 1)[c3]
     return q
 
 

@@ -1,0 +1,172 @@
+/*
+ * g4s_rasterizer.h -- C ABI of the MI355X (gfx950) surfel rasterizer, libg4s_hip.so.
+ *
+ * This is the drop-in boundary for G4Splat's `gaussian_renderer.render()` hot path: the
+ * entry points below are what the reference's torch glue
+ * (dsr/rasterize_points.cu, knn/spatial.cu) binds underneath, with the C++ classes
+ * `CudaRasterizer::Rasterizer` (dsr/cuda_rasterizer/rasterizer.h:24-86) and `SimpleKNN`
+ * (knn/simple_knn.h:15-19) flattened to `extern "C"`:
+ *
+ *   - plain device pointers and sizes, no torch / STL types;
+ *   - the three `std::function<char*(size_t)>` scratch callbacks of
+ *     Rasterizer::forward (rasterizer.h:32-34) become `char* (*)(void* ctx, size_t)`;
+ *   - every launch goes to the caller's `hipStream_t` (passed as `void*`; NULL = the
+ *     null stream) instead of the legacy default stream;
+ *   - errors are an int status + g4s_last_error() instead of C++ exceptions.
+ *
+ * All pointers are device pointers unless stated.  Inputs are borrowed and read-only;
+ * outputs and the scratch chunks are owned by the caller.  "Absent" optional inputs are
+ * NULL (the reference passes empty tensors whose data pointer is null,
+ * dsr/cuda_rasterizer/rasterizer_impl.cu:322-323).  Re-entrant across host threads and
+ * devices (no global mutable state besides a thread-local pinned word).
+ *
+ * dsr/ = 2d-gaussian-splatting/submodules/diff-surfel-rasterization/
+ * knn/ = 2d-gaussian-splatting/submodules/simple-knn/
+ */
+#ifndef G4S_RASTERIZER_H_INCLUDED
+#define G4S_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G4S_OK 0
+#define G4S_ERR_INVALID_ARGUMENT (-1) /* bad shape / NULL required pointer / limit exceeded */
+#define G4S_ERR_HIP (-2)              /* a HIP runtime call or kernel launch failed */
+#define G4S_ERR_ALLOC (-3)            /* a resize callback returned NULL */
+#define G4S_ERR_UNSUPPORTED (-4)      /* e.g. NUM_CHANNELS != 3 without precomputed colours */
+
+/* Scratch-chunk resize callback: must return a device pointer to at least `nbytes`
+ * bytes (any alignment; the library aligns sub-allocations to 256 B itself) that stays
+ * valid until the matching backward call.  Replaces std::function<char*(size_t)>
+ * (dsr/cuda_rasterizer/rasterizer.h:32-34, dsr/rasterize_points.cu:31-37). */
+typedef char* (*g4s_resize_fn)(void* ctx, size_t nbytes);
+
+/* Message of the last error raised on the calling thread ("" if none). */
+const char* g4s_last_error(void);
+
+/* Version / build identification: "g4s-hip <semver> gfx950". */
+const char* g4s_version(void);
+
+/*
+ * Forward rasterisation.  Replaces CudaRasterizer::Rasterizer::forward
+ * (dsr/cuda_rasterizer/rasterizer.h:30-56, rasterizer_impl.cu:198-342).
+ *
+ *   P, D, M          #Gaussians, active SH degree (0..3), SH coefficients per Gaussian in memory
+ *   background[3], width, height
+ *   means3D[P,3], shs[P,M,3] or NULL, colors_precomp[P,3] or NULL, opacities[P],
+ *   scales[P,2] or NULL, scale_modifier, rotations[P,4] (w,x,y,z) or NULL,
+ *   transMat_precomp[P,9] or NULL, viewmatrix[16], projmatrix[16], cam_pos[3],
+ *   tan_fovx, tan_fovy, prefiltered (accepted, ignored: the reference only traps on it)
+ *   out_color[3,H,W], out_others[7,H,W] (channel map dsr/cuda_rasterizer/auxiliary.h:23-27),
+ *   radii[P] int32 or NULL
+ *   debug != 0: synchronise and check after every launch (CHECK_CUDA, auxiliary.h:295-302)
+ *
+ * Outputs need no pre-initialisation (the library writes every element).
+ * Returns num_rendered (>= 0; the number of (Gaussian, tile) instances, identical to the
+ * reference's) or a negative G4S_ERR_*.  Contains ONE host synchronisation (reading
+ * num_rendered to size the binning chunk), exactly like the reference
+ * (rasterizer_impl.cu:281-282).
+ * Limit: ceil(W/16)*ceil(H/16) <= 65536 tiles.
+ */
+int g4s_rasterizer_forward(
+    g4s_resize_fn geometry_buffer, void* geometry_ctx,
+    g4s_resize_fn binning_buffer, void* binning_ctx,
+    g4s_resize_fn image_buffer, void* image_ctx,
+    int P, int D, int M,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_others, int* radii, int debug, void* stream);
+
+/* Bytes of transient workspace g4s_rasterizer_backward needs for a forward that
+ * returned R (per-instance gradient records, 72 B each + alignment). */
+size_t g4s_rasterizer_backward_workspace(int P, int R);
+
+/*
+ * Backward.  Replaces CudaRasterizer::Rasterizer::backward
+ * (dsr/cuda_rasterizer/rasterizer.h:58-85, rasterizer_impl.cu:346-448).
+ *
+ *   geom_buffer / binning_buffer / image_buffer : the chunks the forward call filled
+ *   R : the forward's return value
+ *   dL_dpix[3,H,W], dL_depths[7,H,W] : cotangents of out_color / out_others
+ *   workspace : >= g4s_rasterizer_backward_workspace(P,R) bytes, contents undefined
+ *   outputs (all fully written, no pre-zeroing needed; rows of invisible Gaussians = 0):
+ *     dL_dmean2D[P,3]  (densification surrogate, backward.cu:637-640; .z = 0)
+ *     dL_dnormal[P,3], dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3],
+ *     dL_dtransMat[P,9], dL_dsh[P,M,3] (if M > 0), dL_dscale[P,2], dL_drot[P,4]
+ * Deterministic (no floating-point atomics), unlike the reference.
+ * Returns G4S_OK or a negative G4S_ERR_*.
+ */
+int g4s_rasterizer_backward(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths,
+    float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    char* workspace, size_t workspace_bytes, int debug, void* stream);
+
+/* Near-plane visibility.  Replaces CudaRasterizer::Rasterizer::markVisible
+ * (dsr/cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:54-66,141-153).
+ * present[P] is one byte per Gaussian (bool). */
+int g4s_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                                const float* projmatrix, uint8_t* present, void* stream);
+
+/* Bytes of scratch g4s_knn_mean_dist needs for P points. */
+size_t g4s_knn_workspace(int P);
+
+/* Mean squared distance to the three nearest other points.  Replaces SimpleKNN::knn
+ * (knn/simple_knn.h:18, knn/simple_knn.cu:185-221); unlike the reference it allocates
+ * nothing itself: `workspace` must hold g4s_knn_workspace(P) bytes.
+ * points[P,3], meanDists[P].  No host synchronisation (the bounding box stays on the device). */
+int g4s_knn_mean_dist(int P, const float* points, float* meanDists, char* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- diagnostics (used by the parity tests to compare stage by stage) ---------------- */
+
+/* Describes where the forward call put its private state inside the three chunks so a
+ * test can read it back.  Offsets are relative to the chunk base returned by the resize
+ * callbacks.  Not part of the drop-in surface. */
+typedef struct g4s_layout {
+    /* geometry chunk */
+    size_t rec;          /* P x 20 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb */
+    size_t clamped;      /* P x u8 (bit c = channel c clamped) */
+    size_t depth_sorted; /* P x u32 Gaussian indices in (depth, index) order, culled ones last */
+    size_t tiles_touched;/* P x u32 */
+    size_t geom_bytes;
+    /* binning chunk */
+    size_t entries;      /* R x u64 sorted instances: tile<<48 | k<<32 | idx */
+    size_t binning_bytes;
+    /* image chunk */
+    size_t ranges;       /* tiles x (u32 start, u32 end) */
+    size_t final_T;      /* 3N floats: T, M1, M2 */
+    size_t n_contrib;    /* 2N u32: last contributor, median contributor */
+    size_t image_bytes;
+} g4s_layout;
+
+int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py
+ * for the roofline figure; off by default, process-wide).  Kernel groups 0..g4s_profile_kernels()-1
+ * are named by g4s_profile_name().  g4s_profile_read() synchronises on the recorded events and
+ * returns the summed duration in milliseconds and the number of recordings. */
+void g4s_profile_enable(int on);
+int g4s_profile_kernels(void);
+const char* g4s_profile_name(int id);
+int g4s_profile_read(int id, double* total_ms, int* count);
+void g4s_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G4S_RASTERIZER_H_INCLUDED */

@@ -1,0 +1,173 @@
+"""HIP path vs CPU oracle on identical seeded inputs, through the C ABI (`_C` front-end).
+
+Tolerances (BASELINE.json north_star): outputs <= 1e-4 abs, gradients <= 1e-3 rel
+(rel = max|a-b| / max|b| per gradient tensor).  Integer/index results (radii, num_rendered,
+per-tile sorted lists, tile ranges, contributor counts) must be identical."""
+import numpy as np
+import pytest
+
+from common import EMPTY, cotangents, hip_state, rel_err, run_hip, run_oracle, scene_inputs
+
+pytestmark = pytest.mark.gpu
+
+OUT_ATOL = 1e-4
+GRAD_RTOL = 1e-3
+
+
+def check_forward(h, o):
+    assert h["R"] == o["R"]
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    assert np.abs(h["color"] - o["color"]).max() <= OUT_ATOL
+    for c in range(7):
+        assert np.abs(h["others"][c] - o["others"][c]).max() <= OUT_ATOL, f"others[{c}]"
+
+
+def check_grads(h, o):
+    for name in ("means3D", "scales", "rotations", "opacity", "sh", "colors", "transMat", "means2D"):
+        if o["grads"][name].size == 0:
+            assert h["grads"][name].size == 0
+            continue
+        assert h["grads"][name].shape == o["grads"][name].shape, name
+        assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, name
+
+
+def test_stages_match_oracle(hip_lib, oracle_mod):
+    """Every intermediate product of the forward: records, depth order, sorted lists, ranges, state."""
+    inp = scene_inputs(P=4000, W=200, H=136, seed=11, D=3, bg=(0.1, 0.3, 0.6), scale_mul=2.0)
+    o = run_oracle(oracle_mod, inp)
+    h = run_hip(inp)
+    st = hip_state(h, inp)
+    orc = o["oracle"]
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(st["tiles_touched"], orc.state("tiles_touched"))
+    rec = st["rec"]
+    # per-Gaussian records: same arithmetic on both sides => bitwise equal
+    np.testing.assert_array_equal(rec[vis, 0:2], orc.state("means2D")[vis])
+    np.testing.assert_array_equal(rec[vis, 4:8], orc.state("normal_opacity")[vis])
+    np.testing.assert_array_equal(rec[vis, 8:17], orc.state("transMat")[vis])
+    np.testing.assert_array_equal(rec[vis, 17:20], orc.state("rgb")[vis])
+    clamped = orc.state("clamped")
+    bits = clamped[:, 0] | (clamped[:, 1] << 1) | (clamped[:, 2] << 2)
+    np.testing.assert_array_equal(st["clamped"][vis], bits[vis])
+    # sorted per-tile lists and ranges
+    ent = st["entries"]
+    np.testing.assert_array_equal((ent & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+                                  orc.state("point_list"))
+    np.testing.assert_array_equal((ent >> np.uint64(48)).astype(np.uint32),
+                                  (orc.state("keys") >> np.uint64(32)).astype(np.uint32))
+    np.testing.assert_array_equal(st["ranges"], orc.state("ranges"))
+    np.testing.assert_array_equal(st["n_contrib"], orc.state("n_contrib"))
+    assert np.abs(st["final_T"] - orc.state("final_T")).max() <= OUT_ATOL
+    check_forward(h, o)
+
+
+@pytest.mark.parametrize("D", [0, 1, 2, 3])
+def test_config1_forward_backward(hip_lib, oracle_mod, D):
+    """BASELINE config 1: 10k random Gaussians, one 256x256 pinhole camera."""
+    inp = scene_inputs(P=10000, W=256, H=256, seed=0, D=D, bg=(0.0, 0.0, 0.0) if D % 2 else (0.4, 0.2, 0.9))
+    g = cotangents(256, 256)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    check_forward(h, o)
+    check_grads(h, o)
+
+
+def test_ragged_image_and_scale_modifier(hip_lib, oracle_mod):
+    inp = scene_inputs(P=3000, W=250, H=131, seed=5, D=2, bg=(1.0, 1.0, 1.0), scale_mul=1.5, scale_modifier=0.7)
+    g = cotangents(131, 250, seed=3)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    check_forward(h, o)
+    check_grads(h, o)
+
+
+def test_precomputed_colors_and_transmat(hip_lib, oracle_mod):
+    """colors_precomp / transMat_precomp paths (absent SH, absent scale+rotation)."""
+    inp = scene_inputs(P=2000, W=128, H=96, seed=9, D=0, scale_mul=2.0)
+    o0 = run_oracle(oracle_mod, inp)
+    rng = np.random.default_rng(4)
+    inp2 = dict(inp)
+    inp2["colors"] = rng.uniform(0, 1, (2000, 3)).astype(np.float32)
+    inp2["sh"] = EMPTY
+    inp2["transMat"] = o0["oracle"].state("transMat")
+    inp2["scales"] = EMPTY
+    inp2["rotations"] = EMPTY
+    g = cotangents(96, 128, seed=8)
+    o = run_oracle(oracle_mod, inp2, g)
+    h = run_hip(inp2, g)
+    check_forward(h, o)
+    check_grads(h, o)
+
+
+def test_empty_and_all_culled(hip_lib, oracle_mod):
+    inp = scene_inputs(P=64, W=64, H=48, seed=2, D=1, bg=(0.3, 0.6, 0.9))
+    # all behind the camera -> R == 0, frame == background, zero gradients
+    inp["means3D"] = inp["means3D"].copy()
+    inp["means3D"][:, 2] = -np.abs(inp["means3D"][:, 2]) - 1.0
+    g = cotangents(48, 64)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    assert h["R"] == 0 and o["R"] == 0
+    check_forward(h, o)
+    for k, v in h["grads"].items():
+        assert not np.any(v), k
+    # P == 0 -> zero-filled outputs (rasterize_points.cu:85-99), no launch
+    inp0 = dict(inp)
+    for k in ("means3D", "opacity", "scales", "rotations", "sh"):
+        inp0[k] = inp[k][:0]
+    h0 = run_hip(inp0, g)
+    assert h0["R"] == 0 and not np.any(h0["color"]) and not np.any(h0["others"])
+    # M is taken as 0 when sh has no rows (rasterize_points.cu:181-185) => dL_dsh is [0, 0, 3]
+    assert h0["grads"]["means3D"].shape == (0, 3) and h0["grads"]["sh"].shape == (0, 0, 3)
+
+
+def test_equal_depth_ties_and_tile_clipping(hip_lib, oracle_mod):
+    """Stable-sort tie order (ascending index) and the 3-sigma tile-rect clipping of opaque splats."""
+    P = 6
+    means = np.array([[0.0, 0.0, 2.0], [0.02, 0.01, 2.0], [0.3, 0.2, 2.0], [0.31, 0.2, 2.0], [-0.4, 0.1, 3.0],
+                      [-0.4, 0.1, 3.0]], np.float32)
+    inp = scene_inputs(P=P, W=96, H=64, seed=1, D=0)
+    inp["means3D"] = means
+    inp["scales"] = np.full((P, 2), 0.12, np.float32)
+    inp["rotations"] = np.tile(np.array([[1, 0, 0, 0]], np.float32), (P, 1))
+    inp["opacity"] = np.full((P, 1), 0.97, np.float32)
+    g = cotangents(64, 96, seed=2)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    st = hip_state(h, inp)
+    np.testing.assert_array_equal((st["entries"] & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+                                  o["oracle"].state("point_list"))
+    check_forward(h, o)
+    check_grads(h, o)
+
+
+def test_backward_is_deterministic(hip_lib):
+    """No float atomics: two backward passes over the same forward state agree bit for bit."""
+    inp = scene_inputs(P=5000, W=160, H=160, seed=21, D=3)
+    g = cotangents(160, 160)
+    a = run_hip(inp, g)
+    b = run_hip(inp, g)
+    for k in a["grads"]:
+        np.testing.assert_array_equal(a["grads"][k], b["grads"][k])
+
+
+def test_mark_visible(hip_lib, oracle_mod):
+    import torch
+    from g4splat_amd.diff_surfel_rasterization import _C
+    inp = scene_inputs(P=5000, seed=3)
+    got = _C.mark_visible(torch.as_tensor(inp["means3D"], device="cuda"), torch.as_tensor(inp["view"], device="cuda"),
+                          torch.as_tensor(inp["proj"], device="cuda")).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle_mod.mark_visible(inp["means3D"], inp["view"], inp["proj"]))
+
+
+@pytest.mark.parametrize("P", [1, 3, 4, 1000, 5000])
+def test_distCUDA2(hip_lib, oracle_mod, P):
+    import torch
+    from g4splat_amd.simple_knn._C import distCUDA2
+    rng = np.random.default_rng(P)
+    pts = rng.normal(size=(P, 3)).astype(np.float32)
+    if P >= 1000:
+        pts[10] = pts[11]  # a duplicate: distance 0 participates
+    got = distCUDA2(torch.as_tensor(pts, device="cuda")).cpu().numpy()
+    want = oracle_mod.distCUDA2(pts)
+    np.testing.assert_array_equal(got, want)
