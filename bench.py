@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py -- rasterized Gaussians/s, forward+backward, on MI355X.
+
+A "step" is one pass of the hot path over one training view: one
+`_C.rasterize_gaussians` + one `_C.rasterize_gaussians_backward` on
+synthetic data already resident in HBM; with N > 1 ranks every rank renders its own view
+of the replicated scene and the step also all-reduces the parameter gradients over RCCL
+(one view per GPU, weak scaling).
+
+Workload at N=1 (BASELINE.json metric "rasterized Gaussians/s fwd+bwd @1600x1200"):
+S3 = configs[2] stand-in: 1.5 M surfels on the faces of a 6x4x3 m room, 1600x1200, SH degree 3.
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+`roofline` for the dominant kernel and `cpu_baseline` (the CPU oracle timed on the host
+cores on a bounded sample; reported baseline, not a target).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (P, W, H, SH degree, #views)
+    "s3": (1_500_000, 1600, 1200, 3, 8),   # ScanNet++-like, BASELINE configs[2] (metric resolution)
+    "s2": (300_000, 1200, 680, 3, 8),      # Replica-room0-like, configs[1]/[3]
+    "s1": (10_000, 256, 256, 3, 1),        # configs[0]
+    "s5": (3_000_000, 1200, 680, 3, 8),    # DeepBlending-like, configs[4]
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_scene(name, device):
+    from g4splat_amd import synthetic
+    P, W, H, D, nviews = WORKLOADS[name]
+    if name == "s1":
+        scene, cam = synthetic.scene_random(P, seed=0, width=W, height=H)
+        cams = [cam]
+    else:
+        scene = synthetic.scene_room(P, seed=0)
+        cams = synthetic.room_cameras(nviews, W, H, fovx_deg=90.0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
+    dev = dict(means3D=t(scene.means3D), scales=t(scene.scales), rotations=t(scene.rotations),
+               opacity=t(scene.opacities), sh=t(scene.shs))
+    dcams = [dict(view=t(c.world_view_transform), proj=t(c.full_proj_transform), campos=t(c.camera_center),
+                  tanfovx=c.tanfovx, tanfovy=c.tanfovy) for c in cams]
+    return scene, cams, dev, dcams, (P, W, H, D)
+
+
+def algorithmic_bytes(kernel, P, V, R, N, K, M, tiles, tile_bits):
+    """SURVEY.md 8(d) per-kernel algorithmic bytes of one forward+backward."""
+    p_s = (tile_bits + 7) // 8
+    return {
+        "preprocess_fwd": P * (44 + 4 + 4 + 8) + V * (12 * K + 76),
+        "blend_fwd": R * 76 + N * 60,
+        "blend_bwd": R * 76 + N * 60 + V * 72,
+        "preprocess_bwd": V * (44 + 12 * K + 72 + 36 + 3) + P * (12 + 12 + 8 + 16 + 4) + P * 12 * M + V * 12 * K,
+        "tile_sort": R * 24 * p_s,
+        "emit": R * 12,
+        "tile_ranges": R * 8 + tiles * 8,
+    }.get(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="s3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from g4splat_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    from g4splat_amd.diff_surfel_rasterization import _C
+
+    scene, cams, dev, dcams, (P, W, H, D) = build_scene(args.workload, device)
+    N = W * H
+    bg = torch.zeros(3, device=device)
+    empty = torch.empty(0, device=device)
+    g = torch.Generator(device=device).manual_seed(1)
+    dL_dcolor = torch.randn((3, H, W), device=device, generator=g)
+    dL_dothers = torch.randn((7, H, W), device=device, generator=g)
+
+    def step(i):
+        cam = dcams[(rank + i * world) % len(dcams)]
+        fw = _C.rasterize_gaussians(bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0,
+                                    empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"], H, W, dev["sh"],
+                                    D, cam["campos"], False, False)
+        R, color, others, radii, geom, binning, img = fw
+        grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
+                                                1.0, empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"],
+                                                dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
+                                                img, False)
+        if dist is not None:
+            # SUM of the parameter gradients (xyz, SH, opacity, scale, rotation = 58 floats per
+            # Gaussian) + densification side channel (per-view ||grad_means2D||, visibility count, max radii)
+            gm2, _gc, gop, gm3, _gt, gsh, gsc, grot = grads
+            stats = torch.stack([gm2[:, :2].norm(dim=1), (radii > 0).float()], 1)
+            works = [dist.all_reduce(t, async_op=True) for t in (gm3, gsh, gop, gsc, grot, stats)]
+            rmax = radii.clone()
+            works.append(dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True))
+            for w_ in works:
+                w_.wait()
+        return R, radii
+
+    # warm-up (also measures V and R per view outside the timed region)
+    Vs, Rs = {}, {}
+    for i in range(max(args.warmup, 1)):
+        R, radii = step(i)
+        c = (rank + i * world) % len(dcams)
+        Vs[c] = int((radii > 0).sum().item())
+        Rs[c] = int(R)
+    for i in range(len(dcams)):  # make sure every view that the timed steps use has its V known
+        c = (rank + i * world) % len(dcams)
+        if c not in Vs and i < args.steps:
+            R, radii = step(i)
+            Vs[c] = int((radii > 0).sum().item())
+            Rs[c] = int(R)
+
+    timing = not args.no_kernel_timing
+    lib.g4s_profile_reset()
+    lib.g4s_profile_enable(1 if timing else 0)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.g4s_profile_enable(0)
+
+    units = sum(Vs[(rank + i * world) % len(dcams)] for i in range(args.steps))
+    inst = sum(Rs[(rank + i * world) % len(dcams)] for i in range(args.steps))
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        uu = torch.tensor([units, inst], device=device, dtype=torch.float64)
+        dist.all_reduce(uu)
+        units, inst = int(uu[0].item()), int(uu[1].item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    import ctypes
+    kernels_ms = {}
+    if timing:
+        for k in range(lib.g4s_profile_kernels()):
+            ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
+            lib.g4s_profile_read(k, ctypes.byref(ms), ctypes.byref(cnt))
+            if cnt.value:
+                kernels_ms[lib.g4s_profile_name(k).decode()] = ms.value / cnt.value
+        lib.g4s_profile_reset()
+
+    # roofline of the dominant kernel (rank 0's view mix)
+    roofline = None
+    if kernels_ms:
+        dom = max((k for k in kernels_ms if algorithmic_bytes(k, 1, 1, 1, 1, 1, 1, 1, 8) is not None),
+                  key=lambda k: kernels_ms[k])
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        tile_bits = max(1, math.ceil(math.log2(tiles + 1)))
+        views = [(0 + i * world) % len(dcams) for i in range(args.steps)]
+        Vm = sum(Vs[c] for c in views) / len(views)
+        Rm = sum(Rs[c] for c in views) / len(views)
+        B = algorithmic_bytes(dom, P, Vm, Rm, N, (D + 1) ** 2, 16, tiles, tile_bits)
+        achieved = B / (kernels_ms[dom] * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(B), "avg_launch_ms": round(kernels_ms[dom], 4)}
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu_baseline = run_cpu_baseline(scene, cams[0], P, W, H, D)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": "rasterized Gaussians/s fwd+bwd @1600x1200" if args.workload == "s3"
+        else f"rasterized Gaussians/s fwd+bwd @{W}x{H}",
+        "value": units / elapsed, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {P} surfels (room box), {W}x{H}, SH degree {D}, "
+                               f"{len(dcams)} views, 1 view/GPU/step", "P": P, "width": W, "height": H,
+                   "sh_degree": D, "visible_per_view": round(units / args.steps / world),
+                   "instances_per_view": round(inst / args.steps / world),
+                   "parallelism": f"view-dp{world}" + ("+rccl-allreduce" if world > 1 else "")},
+        "gaussians_total_per_s": P * args.steps * world / elapsed,
+        "instances_per_s": inst / elapsed,
+        "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(scene, cam, P, W, H, D, target_gaussians=150_000):
+    """CPU restatement of the reference algorithm (oracle/, 'port') on the host cores, bounded sample:
+    a seeded subset of the same scene, same camera and resolution."""
+    from oracle import oracle as om
+    om.build()
+    n = min(P, target_gaussians)
+    idx = np.random.default_rng(0).choice(P, n, replace=False) if n < P else np.arange(P)
+    e = np.zeros((0,), np.float32)
+    rng = np.random.default_rng(1)
+    gc = rng.normal(size=(3, H, W)).astype(np.float32)
+    go = rng.normal(size=(7, H, W)).astype(np.float32)
+    o = om.Oracle()
+    t0 = time.perf_counter()
+    R, _, _, radii = o.rasterize_gaussians(np.zeros(3, np.float32), scene.means3D[idx], e, scene.opacities[idx],
+                                           scene.scales[idx], scene.rotations[idx], 1.0, e, cam.world_view_transform,
+                                           cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, scene.shs[idx], D,
+                                           cam.camera_center)
+    o.rasterize_gaussians_backward(gc, go)
+    dt = time.perf_counter() - t0
+    V = int((radii > 0).sum())
+    return {"value": V / dt, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} of {P} surfels (seeded subset), same view 0 at {W}x{H}, 1 fwd+bwd, "
+                      f"{V} visible, {R} instances, {dt:.2f} s, OpenMP over all host cores"}
+
+
+if __name__ == "__main__":
+    main()

@@ -218,6 +218,8 @@ extern "C" int g4s_rasterizer_forward(
         pa.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16));
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
         pa.depth_keys = keys_a; pa.gidx = vals_a;
+        pa.ref_total = d_total + 1;
+        HIP_TRY(hipMemsetAsync(d_total, 0, 8, stream));
         { ProfScope ps(PF_PREPROCESS_FWD, stream); launch_preprocess_fwd(pa, stream); }
         CHECK_LAUNCH("preprocess_fwd");
 
@@ -236,10 +238,14 @@ extern "C" int g4s_rasterizer_forward(
         // the one host synchronisation of the forward (rasterizer_impl.cu:281-282)
         uint32_t* h_total = pinned_word();
         if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
-        HIP_TRY(hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (*h_total > 0x7FFFFFFFu) return fail(G4S_ERR_INVALID_ARGUMENT, "num_rendered overflows int");
-        R = (int)*h_total;
+        // h_total[0]: instances actually binned (3-sigma rect intersected with the alpha-cutoff box),
+        // h_total[1]: the reference's count (3-sigma rect only) = the num_rendered this call returns.
+        // All buffers are laid out for the reference count, which bounds the binned one.
+        if (h_total[1] > 0x7FFFFFFFu) return fail(G4S_ERR_INVALID_ARGUMENT, "num_rendered overflows int");
+        R = (int)h_total[1];
+        const int R_binned = (int)h_total[0];
 
         const BinLayout BL = bin_layout((size_t)R);
         char* bin = binning_buffer(binning_ctx, BL.bytes);
@@ -248,7 +254,7 @@ extern "C" int g4s_rasterizer_forward(
         uint64_t* ent_a = (uint64_t*)(bin + BL.ent_a);
         uint64_t* ent_b = (uint64_t*)(bin + BL.ent_b);
         entries_ptr = ent_a;
-        if (R > 0) {
+        if (R_binned > 0) {
             { ProfScope ps(PF_EMIT, stream);
               launch_emit(P, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, GL.nblocks,
                           stream); }
@@ -256,11 +262,12 @@ extern "C" int g4s_rasterizer_forward(
             const int tile_bits = (int)higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:301
             int c2;
             { ProfScope ps(PF_TILE_SORT, stream);
-              c2 = radix_sort_u64_keys(ent_a, ent_b, R, ENTRY_TILE_SHIFT, ENTRY_TILE_SHIFT + tile_bits,
-                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total), BL.nchunks, stream); }
+              c2 = radix_sort_u64_keys(ent_a, ent_b, R_binned, ENTRY_TILE_SHIFT, ENTRY_TILE_SHIFT + tile_bits,
+                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total),
+                                       (R_binned + SORT_CHUNK - 1) / SORT_CHUNK, stream); }
             CHECK_LAUNCH("tile partition");
             entries_ptr = c2 ? ent_b : ent_a;
-            { ProfScope ps(PF_TILE_RANGES, stream); launch_tile_ranges(R, entries_ptr, ranges, stream); }
+            { ProfScope ps(PF_TILE_RANGES, stream); launch_tile_ranges(R_binned, entries_ptr, ranges, stream); }
             CHECK_LAUNCH("tile ranges");
         }
         rec_ptr = rec;
@@ -282,7 +289,7 @@ extern "C" int g4s_rasterizer_forward(
 
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
     (void)P;
-    return align_up((size_t)(R > 0 ? R : 1) * GRAD_FLOATS * 4) + 256;
+    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + 256;
 }
 
 extern "C" int g4s_rasterizer_backward(
@@ -300,7 +307,7 @@ extern "C" int g4s_rasterizer_backward(
     if (P == 0) return G4S_OK;  // rasterize_points.cu:197: nothing to do, outputs are [0,*]
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
         return fail(G4S_ERR_INVALID_ARGUMENT, "state buffers must not be NULL");
-    if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dnormal || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
+    if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
         !dL_dtransMat || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
         return fail(G4S_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
     if (workspace_bytes < g4s_rasterizer_backward_workspace(P, R) || !workspace)

@@ -231,8 +231,11 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
         idx = gidx[r];
         cnt = tiles_touched[idx];
         if (cnt > 0) {
-            const float4 q0 = reinterpret_cast<const float4*>(rec)[(size_t)idx * 5];
-            get_rect(q0.x, q0.y, radii[idx], tiles_x, tiles_y, x0, y0, x1, y1);
+            const float4* rq = reinterpret_cast<const float4*>(rec) + (size_t)idx * REC_QUADS;
+            const float4 q0 = rq[0], q5 = rq[5];
+            int rx0, ry0, rx1, ry1;
+            get_rect(q0.x, q0.y, radii[idx], tiles_x, tiles_y, rx0, ry0, rx1, ry1);
+            tight_tile_rect(q5, rx0, ry0, rx1, ry1, x0, y0, x1, y1);  // same arithmetic as the preprocess
         }
     }
     uint32_t block_total;

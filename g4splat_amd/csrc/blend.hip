@@ -1,92 +1,78 @@
-// Front-to-back alpha blending (K6) and its backward (K7): one 16x16 tile per 256-thread
-// workgroup = four wave64s, each wave owning an 8x8 pixel quadrant.
+// Front-to-back alpha blending (K6) and its backward (K7) over 16x16 tiles.
 //
 // Reference semantics: dsr/cuda_rasterizer/forward.cu:258-443, backward.cu:143-440.
 //
 // MI355X design:
-//   * the tile's sorted instance list is staged through LDS in batches of 256 splat records
-//     (80 B each, fetched as five 16-byte quads per thread, stored SoA so that the inner loop
-//     reads them with conflict-free broadcast ds_read_b128);
-//   * wave64 quadrants (8x8) instead of 16x2 warp strips: a quadrant stops as soon as its 64
-//     pixels are saturated / skips a splat as soon as no lane passes the alpha test;
-//   * backward: no global float atomics.  The 18 per-(pixel,splat) gradient terms are summed
-//     across the 64 lanes with DPP row operations, across the 4 waves in LDS, and stored as
-//     ONE 72-byte record per (tile, Gaussian) instance at a slot reserved for that Gaussian
-//     (inst_off + k).  The per-Gaussian kernel (preprocess.hip, K8) folds a Gaussian's
-//     contiguous records in a fixed order => bit-reproducible gradients.
+//   * a tile's sorted instance list is staged through LDS as 96-byte splat records (six 16-byte
+//     quads per entry, SoA in LDS so the inner loop reads them with conflict-free broadcast
+//     ds_read_b128);
+//   * pixels are grouped in wave64-sized 8x8 quadrants.  Before any per-pixel arithmetic a
+//     quadrant is tested against the splat's alpha-cutoff box (record quad 5) with wave-uniform
+//     compares, and every expensive stage sits behind a wave-uniform __any();
+//   * forward: 4 waves per tile, one quadrant each; a quadrant stops as soon as its 64 pixels are
+//     saturated;
+//   * backward: no float atomics anywhere.  ONE wave owns a whole tile, every lane owns four pixels
+//     (the same position in each quadrant): the sum over the tile's 256 pixels is 3 in-register
+//     adds plus one wave reduction built from gfx950's v_permlane32_swap / v_permlane16_swap
+//     (four values per 10 instructions), written as ONE 80-byte record per (tile, Gaussian)
+//     instance at a slot reserved for that Gaussian (inst_off + k).  The per-Gaussian kernel
+//     (preprocess.hip, K8) folds a Gaussian's contiguous records in a fixed order
+//     => bit-reproducible gradients, no workgroup barriers in the hot loop.
 #include "g4s_internal.h"
 #include "g4s_device.h"
 
 namespace g4s {
 
-constexpr int BATCH = 256;
-
-struct PixelCoord {
-    int px, py;
-    bool inside;
-};
-__device__ __forceinline__ PixelCoord pixel_of_thread(int tile_x, int tile_y, int W, int H) {
-    const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63);
-    PixelCoord c;
-    c.px = tile_x * TILE + (w & 1) * 8 + (l & 7);
-    c.py = tile_y * TILE + (w >> 1) * 8 + (l >> 3);
-    c.inside = c.px < W && c.py < H;
-    return c;
-}
-
-// Stage one batch of splat records: thread t fetches list entry `pos` (if valid).
-__device__ __forceinline__ void stage_record(const uint64_t* __restrict__ entries, const float* __restrict__ rec,
-                                             uint32_t pos, bool valid, float4 (*s_rec)[BATCH], uint32_t* s_slot) {
-    const int t = (int)threadIdx.x;
-    if (valid) {
-        const uint64_t e = entries[pos];
-        const uint32_t idx = entry_idx(e);
-        const float4* r = reinterpret_cast<const float4*>(rec) + (size_t)idx * 5;
-        const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
-        s_rec[0][t] = q0;
-        s_rec[1][t] = q1;
-        s_rec[2][t] = q2;
-        s_rec[3][t] = q3;
-        s_rec[4][t] = q4;
-        if (s_slot) s_slot[t] = __float_as_uint(q0.z) + entry_k(e);  // inst_off + k
-    }
+// true if the 8x8 pixel quadrant [qx, qx+7] x [qy, qy+7] misses the splat's alpha-cutoff box
+__device__ __forceinline__ bool quad_misses_box(const float4 box, float qx, float qy) {
+    return box.x > qx + 7.0f || box.z < qx || box.y > qy + 7.0f || box.w < qy;
 }
 
 // ---------------------------------------------------------------------------------------
 // K6 forward
 
+constexpr int FWD_BATCH = 256;
+
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
-    __shared__ float4 s_rec[5][BATCH];
+    __shared__ float4 s_rec[REC_QUADS][FWD_BATCH];
     const int tile = (int)blockIdx.x;
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    const PixelCoord pc = pixel_of_thread(tile_x, tile_y, a.W, a.H);
-    const float pxf = (float)pc.px, pyf = (float)pc.py;
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int qx = tile_x * TILE + (wv & 1) * 8, qy = tile_y * TILE + (wv >> 1) * 8;
+    const int px = qx + (lane & 7), py = qy + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const float pxf = (float)px, pyf = (float)py, qxf = (float)qx, qyf = (float)qy;
     const size_t N = (size_t)a.W * a.H;
-    const size_t pix_id = (size_t)a.W * pc.py + pc.px;
+    const size_t pix_id = (size_t)a.W * py + px;
 
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int n = (int)(r1 - r0);
-    bool done = !pc.inside;
+    bool done = !inside;
 
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0, median_contributor = 0;
+    uint32_t last_contributor = 0, median_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0;
     float Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
 
-    for (int b0 = 0; b0 < n; b0 += BATCH) {
+    for (int b0 = 0; b0 < n; b0 += FWD_BATCH) {
         // end if the entire tile is saturated (forward.cu:327)
         if (__syncthreads_count(done) == 256) break;
-        const int m = imin_(BATCH, n - b0);
-        stage_record(a.entries, a.rec, r0 + b0 + threadIdx.x, (int)threadIdx.x < m, s_rec, nullptr);
+        const int m = imin_(FWD_BATCH, n - b0);
+        if ((int)threadIdx.x < m) {
+            const uint64_t e = a.entries[r0 + b0 + threadIdx.x];
+            const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
+#pragma unroll
+            for (int i = 0; i < REC_QUADS; i++) s_rec[i][threadIdx.x] = r[i];
+        }
         __syncthreads();
         if (__all(done)) continue;  // this quadrant is finished; keep taking part in the staging
         for (int j = 0; j < m; j++) {
-            if (done) {
-                if (__all(done)) break;
-                continue;
-            }
-            contributor = (uint32_t)(b0 + j + 1);
+            if (__all(done)) break;
+            if (quad_misses_box(s_rec[5][j], qxf, qyf)) continue;  // wave-uniform
+            if (done) continue;
+            // `contributor` of the reference = 1-based list position (forward.cu:349)
+            const uint32_t contributor = (uint32_t)(b0 + j + 1);
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
             PairEval e;
             if (!eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e))
@@ -99,26 +85,26 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
             }
             const float w = alpha * T;
             const float A = 1 - T;
-            const float md = mscale * (1 - NEAR_N / depth);
+            const float md = mscale * (1 - NEAR_N * __builtin_amdgcn_rcpf(depth));
             distortion += (md * md * A + M2 - 2 * md * M1) * w;
-            Dd += depth * w;
-            M1 += md * w;
-            M2 += md * md * w;
+            Dd = fmaf(depth, w, Dd);
+            M1 = fmaf(md, w, M1);
+            M2 = fmaf(md * md, w, M2);
             if (T > 0.5f) {
                 median_depth = depth;
                 median_contributor = contributor;
             }
-            N0 += q1.x * w;
-            N1 += q1.y * w;
-            N2 += q1.z * w;
-            C0 += q4.y * w;
-            C1 += q4.z * w;
-            C2 += q4.w * w;
+            N0 = fmaf(q1.x, w, N0);
+            N1 = fmaf(q1.y, w, N1);
+            N2 = fmaf(q1.z, w, N2);
+            C0 = fmaf(q4.y, w, C0);
+            C1 = fmaf(q4.z, w, C1);
+            C2 = fmaf(q4.w, w, C2);
             T = test_T;
             last_contributor = contributor;
         }
     }
-    if (pc.inside) {
+    if (inside) {
         a.final_T[pix_id] = T;
         a.final_T[pix_id + N] = M1;
         a.final_T[pix_id + 2 * N] = M2;
@@ -127,9 +113,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
         a.out_color[pix_id] = C0 + T * a.bg[0];
         a.out_color[pix_id + N] = C1 + T * a.bg[1];
         a.out_color[pix_id + 2 * N] = C2 + T * a.bg[2];
-        a.out_others[pix_id + 0 * N] = Dd;          // DEPTH_OFFSET
-        a.out_others[pix_id + 1 * N] = 1 - T;       // ALPHA_OFFSET
-        a.out_others[pix_id + 2 * N] = N0;          // NORMAL_OFFSET..+2
+        a.out_others[pix_id + 0 * N] = Dd;            // DEPTH_OFFSET
+        a.out_others[pix_id + 1 * N] = 1 - T;         // ALPHA_OFFSET
+        a.out_others[pix_id + 2 * N] = N0;            // NORMAL_OFFSET..+2
         a.out_others[pix_id + 3 * N] = N1;
         a.out_others[pix_id + 4 * N] = N2;
         a.out_others[pix_id + 5 * N] = median_depth;  // MIDDEPTH_OFFSET
@@ -144,176 +130,202 @@ void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------
 // K7 backward
 
-__global__ void __launch_bounds__(256) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[5][BATCH];
-    __shared__ uint32_t s_slot[BATCH];
-    __shared__ float s_grad[BATCH * GRAD_FLOATS];
-    __shared__ uint32_t s_maxc[4];
+constexpr int BWD_BATCH = 64;
+
+struct BwdPixel {
+    // constants
+    float T_final, final_D, final_D2, bg_dot;
+    uint32_t last_c, median_c;
+    float dpx0, dpx1, dpx2, dL_ddepth, dL_daccum, dL_dreg, dn0, dn1, dn2, dL_dmedian;
+    // running state (back to front)
+    float T, last_alpha, last_v, V_rec, last_dL_dT;
+};
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[REC_QUADS][BWD_BATCH];
+    __shared__ uint32_t s_slot[BWD_BATCH];
 
     const int tile = (int)blockIdx.x;
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
-    const PixelCoord pc = pixel_of_thread(tile_x, tile_y, a.W, a.H);
-    const float pxf = (float)pc.px, pyf = (float)pc.py;
+    const int lane = (int)threadIdx.x;
     const size_t N = (size_t)a.W * a.H;
-    const size_t pix_id = (size_t)a.W * pc.py + pc.px;
-    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
 
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int n = (int)(r1 - r0);
     if (n == 0) return;
 
-    // per-pixel constants
-    float T_final = 0, final_D = 0, final_D2 = 0;
-    uint32_t last_contributor = 0, median_contributor = 0;
-    float dpx0 = 0, dpx1 = 0, dpx2 = 0, dL_ddepth = 0, dL_daccum = 0, dL_dreg = 0, dn0 = 0, dn1 = 0, dn2 = 0,
-          dL_dmedian = 0;
-    if (pc.inside) {
-        T_final = a.final_T[pix_id];
-        final_D = a.final_T[pix_id + N];
-        final_D2 = a.final_T[pix_id + 2 * N];
-        last_contributor = a.n_contrib[pix_id];
-        median_contributor = a.n_contrib[pix_id + N];
-        dpx0 = a.dL_dpix[pix_id];
-        dpx1 = a.dL_dpix[pix_id + N];
-        dpx2 = a.dL_dpix[pix_id + 2 * N];
-        dL_ddepth = a.dL_depths[pix_id + 0 * N];
-        dL_daccum = a.dL_depths[pix_id + 1 * N];
-        dn0 = a.dL_depths[pix_id + 2 * N];
-        dn1 = a.dL_depths[pix_id + 3 * N];
-        dn2 = a.dL_depths[pix_id + 4 * N];
-        dL_dmedian = a.dL_depths[pix_id + 5 * N];
-        dL_dreg = a.dL_depths[pix_id + 6 * N];
+    const int tx0 = tile_x * TILE, ty0 = tile_y * TILE;
+    const int px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+    BwdPixel p[4];
+    uint32_t max_last = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+        BwdPixel& x = p[q];
+        x = BwdPixel{};
+        if (px < a.W && py < a.H) {
+            const size_t pix_id = (size_t)a.W * py + px;
+            x.T_final = a.final_T[pix_id];
+            x.final_D = a.final_T[pix_id + N];
+            x.final_D2 = a.final_T[pix_id + 2 * N];
+            x.last_c = a.n_contrib[pix_id];
+            x.median_c = a.n_contrib[pix_id + N];
+            x.dpx0 = a.dL_dpix[pix_id];
+            x.dpx1 = a.dL_dpix[pix_id + N];
+            x.dpx2 = a.dL_dpix[pix_id + 2 * N];
+            x.dL_ddepth = a.dL_depths[pix_id + 0 * N];
+            x.dL_daccum = a.dL_depths[pix_id + 1 * N];
+            x.dn0 = a.dL_depths[pix_id + 2 * N];
+            x.dn1 = a.dL_depths[pix_id + 3 * N];
+            x.dn2 = a.dL_depths[pix_id + 4 * N];
+            x.dL_dmedian = a.dL_depths[pix_id + 5 * N];
+            x.dL_dreg = a.dL_depths[pix_id + 6 * N];
+        }
+        x.bg_dot = (bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2;
+        x.T = x.T_final;
+        max_last = max(max_last, x.last_c);  // pixels outside the image keep last_c = 0: never active
     }
-    const float final_A = 1 - T_final;
-    const float bg_dot_dpixel = (a.bg[0] * dpx0 + a.bg[1] * dpx1) + a.bg[2] * dpx2;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
+    const bool row_writer = (lane & 15) == 15;
+    const int row = lane >> 4;
 
-    // entries at list positions >= max(last_contributor) over the tile contribute nothing
-    {
-        const uint32_t m = wave_max_u32(last_contributor);
-        if (lane == 0) s_maxc[wv] = m;
-    }
-    __syncthreads();
-    const int n_live = (int)max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
-
-    // zero gradient records for the dead tail [n_live, n)
-    for (int i = n_live * GRAD_FLOATS / 2 + (int)threadIdx.x; i < n * GRAD_FLOATS / 2; i += 256) {
-        const int j = i / (GRAD_FLOATS / 2), q = i - j * (GRAD_FLOATS / 2);
+    // list positions >= max(last_contributor) over the tile contribute nothing: zero records
+    const int n_live = (int)wave_max_u32(max_last);
+    for (int j = n_live + lane; j < n; j += 64) {
         const uint64_t e = a.entries[r0 + j];
-        const uint32_t idx = entry_idx(e);
-        const uint32_t slot = __float_as_uint(a.rec[(size_t)idx * REC_FLOATS + 2]) + entry_k(e);
-        reinterpret_cast<float2*>(a.grad_inst + (size_t)slot * GRAD_FLOATS)[q] = make_float2(0.f, 0.f);
+        const uint32_t slot = __float_as_uint(a.rec[(size_t)entry_idx(e) * REC_FLOATS + 2]) + entry_k(e);
+        float4* dst = reinterpret_cast<float4*>(a.grad_inst + (size_t)slot * GRAD_STRIDE);
+#pragma unroll
+        for (int i = 0; i < GRAD_STRIDE / 4; i++) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // running per-pixel state (back to front)
-    float T = T_final;
-    float last_alpha = 0, last_v = 0, V_rec = 0, last_dL_dT = 0;
-
-    // batches run from the back of the live range: batch b covers list positions
-    // [hi - m, hi), thread t of the staging handles position hi - 1 - t (reverse order)
-    for (int hi = n_live; hi > 0; hi -= BATCH) {
-        const int m = imin_(BATCH, hi);
-        __syncthreads();  // previous batch fully consumed / written out
-        stage_record(a.entries, a.rec, r0 + (uint32_t)(hi - 1 - (int)threadIdx.x), (int)threadIdx.x < m, s_rec, s_slot);
-        for (int i = (int)threadIdx.x; i < m * GRAD_FLOATS; i += 256) s_grad[i] = 0.0f;
+    // batches from the back of the live range; lane t stages list position hi-1-t
+    for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
+        const int m = imin_(BWD_BATCH, hi);
+        __syncthreads();
+        if (lane < m) {
+            const uint64_t e = a.entries[r0 + (uint32_t)(hi - 1 - lane)];
+            const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
+            const float4 q0 = r[0];
+            s_rec[0][lane] = q0;
+#pragma unroll
+            for (int i = 1; i < REC_QUADS; i++) s_rec[i][lane] = r[i];
+            s_slot[lane] = __float_as_uint(q0.z) + entry_k(e);
+        }
         __syncthreads();
 
         for (int j = 0; j < m; j++) {
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-            PairEval e;
-            bool act = pc.inside && pos < last_contributor;
-            if (act)
-                act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
-            if (!__any(act)) continue;  // wave-uniform: nothing to reduce for this splat
-
-            float g[GRAD_FLOATS];
+            const float4 box = s_rec[5][j];
+            float g[GRAD_STRIDE];
 #pragma unroll
-            for (int i = 0; i < GRAD_FLOATS; i++) g[i] = 0.0f;
-            if (act) {
-                const float G = e.G, alpha = e.alpha, c_d = e.depth;
-                const float inv1ma = 1.0f / (1.f - alpha);
-                T = T * inv1ma;                       // T / (1 - alpha), backward.cu:316
-                const float w = alpha * T;
-                // colour / depth / alpha / normal "accum_rec" recurrences (backward.cu:328,362-371)
-                // share their coefficients, so they are folded into one scalar recurrence on
-                // v = <c,dL_dpix> + c_d*dL_ddepth + dL_daccum + <n,dL_dnormal>.
-                const float v = ((q4.y * dpx0 + q4.z * dpx1) + q4.w * dpx2) + c_d * dL_ddepth + dL_daccum +
-                                ((q1.x * dn0 + q1.y * dn1) + q1.z * dn2);
-                V_rec = last_alpha * last_v + (1.f - last_alpha) * V_rec;
-                last_v = v;
-                float dL_dalpha = v - V_rec;
-                g[0] = w * dpx0;
-                g[1] = w * dpx1;
-                g[2] = w * dpx2;
-                g[3] = w * dn0;
-                g[4] = w * dn1;
-                g[5] = w * dn2;
+            for (int i = 0; i < GRAD_STRIDE; i++) g[i] = 0.0f;
+            bool any_active = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (quad_misses_box(box, (float)(tx0 + (q & 1) * 8), (float)(ty0 + (q >> 1) * 8))) continue;  // uniform
+                BwdPixel& x = p[q];
+                const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
+                PairEval e;
+                bool act = pos < x.last_c;
+                if (!__any(act)) continue;
+                if (act)
+                    act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                if (!__any(act)) continue;
+                any_active = true;
+                if (act) {
+                    const float G = e.G, alpha = e.alpha, c_d = e.depth;
+                    const float inv1ma = fast_rcp(1.f - alpha);
+                    x.T = x.T * inv1ma;  // T / (1 - alpha), backward.cu:316
+                    const float T = x.T;
+                    const float w = alpha * T;
+                    // The colour / depth / alpha / normal "accum_rec" recurrences (backward.cu:328,362-371)
+                    // share their coefficients, so they fold into one scalar recurrence on
+                    // v = <c,dL_dpix> + c_d*dL_ddepth + dL_daccum + <n,dL_dnormal>.
+                    const float v = fmaf(q4.y, x.dpx0, fmaf(q4.z, x.dpx1, q4.w * x.dpx2)) +
+                                    fmaf(c_d, x.dL_ddepth, x.dL_daccum) +
+                                    fmaf(q1.x, x.dn0, fmaf(q1.y, x.dn1, q1.z * x.dn2));
+                    x.V_rec = fmaf(x.last_alpha, x.last_v, (1.f - x.last_alpha) * x.V_rec);
+                    x.last_v = v;
+                    float dL_dalpha = v - x.V_rec;
+                    g[0] = fmaf(w, x.dpx0, g[0]);
+                    g[1] = fmaf(w, x.dpx1, g[1]);
+                    g[2] = fmaf(w, x.dpx2, g[2]);
+                    g[3] = fmaf(w, x.dn0, g[3]);
+                    g[4] = fmaf(w, x.dn1, g[4]);
+                    g[5] = fmaf(w, x.dn2, g[5]);
 
-                const float inv_cd = 1.0f / c_d;
-                const float m_d = mscale * (1 - NEAR_N * inv_cd);
-                const float dmd_dd = dmd_k * inv_cd * inv_cd;
-                float dL_dz = (pos + 1 == median_contributor) ? dL_dmedian : 0.0f;
-                const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2 * m_d * final_D) * dL_dreg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = dL_dweight * alpha + (1 - alpha) * last_dL_dT;
-                const float dL_dmd = 2.0f * w * (m_d * final_A - final_D) * dL_dreg;
-                dL_dz += dL_dmd * dmd_dd;
+                    const float final_A = 1 - x.T_final;
+                    const float inv_cd = fast_rcp(c_d);
+                    const float m_d = mscale * (1 - NEAR_N * inv_cd);
+                    const float dmd_dd = dmd_k * inv_cd * inv_cd;
+                    float dL_dz = (pos + 1 == x.median_c) ? x.dL_dmedian : 0.0f;
+                    const float dL_dweight = (x.final_D2 + m_d * m_d * final_A - 2 * m_d * x.final_D) * x.dL_dreg;
+                    dL_dalpha += dL_dweight - x.last_dL_dT;
+                    x.last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * x.last_dL_dT);
+                    const float dL_dmd = 2.0f * w * (m_d * final_A - x.final_D) * x.dL_dreg;
+                    dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
 
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * inv1ma) * bg_dot_dpixel;
-                const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
-                dL_dz += w * dL_ddepth;
+                    dL_dalpha *= T;
+                    x.last_alpha = alpha;
+                    dL_dalpha = fmaf(-x.T_final * inv1ma, x.bg_dot, dL_dalpha);
+                    const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
+                    dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
 
-                if (e.rho3d <= e.rho2d) {
-                    const float dL_dsx = dL_dG * -G * e.sx + dL_dz * q3.z;
-                    const float dL_dsy = dL_dG * -G * e.sy + dL_dz * q3.w;
-                    const float inv_pz = 1.0f / e.pz;
-                    const float dpx_ = dL_dsx * inv_pz, dpy_ = dL_dsy * inv_pz;
-                    const float dpz_ = -(dpx_ * e.sx + dpy_ * e.sy);
-                    // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
-                    const float dkx = e.ly * dpz_ - e.lz * dpy_, dky = e.lz * dpx_ - e.lx * dpz_,
-                                dkz = e.lx * dpy_ - e.ly * dpx_;
-                    const float dlx = dpy_ * e.kz - dpz_ * e.ky, dly = dpz_ * e.kx - dpx_ * e.kz,
-                                dlz = dpx_ * e.ky - dpy_ * e.kx;
-                    g[6] = -dkx;
-                    g[7] = -dky;
-                    g[8] = -dkz;
-                    g[9] = -dlx;
-                    g[10] = -dly;
-                    g[11] = -dlz;
-                    g[12] = pxf * dkx + pyf * dlx + dL_dz * e.sx;
-                    g[13] = pxf * dky + pyf * dly + dL_dz * e.sy;
-                    g[14] = pxf * dkz + pyf * dlz + dL_dz;
-                } else {
-                    g[15] = dL_dG * (-G * FILTER_INV_SQUARE * e.dx);
-                    g[16] = dL_dG * (-G * FILTER_INV_SQUARE * e.dy);
-                    g[14] = dL_dz;
+                    if (e.rho3d <= e.rho2d) {
+                        const float mG = dL_dG * -G;
+                        const float dL_dsx = fmaf(mG, e.sx, dL_dz * q3.z);
+                        const float dL_dsy = fmaf(mG, e.sy, dL_dz * q3.w);
+                        const float inv_pz = fast_rcp(e.pz);
+                        const float dpx_ = dL_dsx * inv_pz, dpy_ = dL_dsy * inv_pz;
+                        const float dpz_ = -fmaf(dpx_, e.sx, dpy_ * e.sy);
+                        // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
+                        const float dkx = fmaf(e.ly, dpz_, -(e.lz * dpy_)), dky = fmaf(e.lz, dpx_, -(e.lx * dpz_)),
+                                    dkz = fmaf(e.lx, dpy_, -(e.ly * dpx_));
+                        const float dlx = fmaf(dpy_, e.kz, -(dpz_ * e.ky)), dly = fmaf(dpz_, e.kx, -(dpx_ * e.kz)),
+                                    dlz = fmaf(dpx_, e.ky, -(dpy_ * e.kx));
+                        g[6] -= dkx;
+                        g[7] -= dky;
+                        g[8] -= dkz;
+                        g[9] -= dlx;
+                        g[10] -= dly;
+                        g[11] -= dlz;
+                        g[12] += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
+                        g[13] += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
+                        g[14] += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
+                    } else {
+                        const float c2 = dL_dG * (-G * FILTER_INV_SQUARE);
+                        g[15] = fmaf(c2, e.dx, g[15]);
+                        g[16] = fmaf(c2, e.dy, g[16]);
+                        g[14] += dL_dz;
+                    }
+                    g[17] = fmaf(G, dL_dalpha, g[17]);
                 }
-                g[17] = G * dL_dalpha;
             }
-            // 64 lanes -> 1 with DPP, 4 waves -> 1 in LDS
+            // 256 pixels -> 1: the four pixels of a lane were summed in registers above, the 64 lanes
+            // are summed four terms at a time; row k of sum_i then holds term 4 i + k.
+            float* dst = a.grad_inst + (size_t)s_slot[j] * GRAD_STRIDE + row;
+            if (any_active) {
 #pragma unroll
-            for (int i = 0; i < GRAD_FLOATS; i++) g[i] = wave_sum_to_lane63(g[i]);
-            if (lane == 63) {
+                for (int i = 0; i < GRAD_STRIDE / 4; i++) {
+                    const float r = wave_sum4_to_rows(g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3]);
+                    if (row_writer) dst[4 * i] = r;
+                }
+            } else if (row_writer) {
 #pragma unroll
-                for (int i = 0; i < GRAD_FLOATS; i++) atomicAdd(&s_grad[j * GRAD_FLOATS + i], g[i]);
+                for (int i = 0; i < GRAD_STRIDE / 4; i++) dst[4 * i] = 0.0f;
             }
-        }
-        __syncthreads();
-        // one 72-byte record per instance
-        for (int i = (int)threadIdx.x; i < m * (GRAD_FLOATS / 2); i += 256) {
-            const int j = i / (GRAD_FLOATS / 2), q = i - j * (GRAD_FLOATS / 2);
-            reinterpret_cast<float2*>(a.grad_inst + (size_t)s_slot[j] * GRAD_FLOATS)[q] =
-                make_float2(s_grad[j * GRAD_FLOATS + 2 * q], s_grad[j * GRAD_FLOATS + 2 * q + 1]);
         }
     }
 }
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.tiles_x * a.tiles_y), dim3(64), 0, s, a);
 }
 
 }  // namespace g4s

@@ -46,6 +46,33 @@ __device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v) {
     v += dpp_u32<0x143, 0xC>(v);
     return v;
 }
+// Sum of FOUR per-lane values over the 64 lanes in 10 VALU instructions (gfx950 permlane swaps):
+// on return every lane of row k (lanes 16k..16k+15) holds the wave total of v_k.
+//   v_permlane32_swap a,b : a' = [a.lo32, b.lo32], b' = [a.hi32, b.hi32]   => a'+b' = [a.lo+a.hi | b.lo+b.hi]
+//   v_permlane16_swap p,q : p' = [p.r0, q.r0, p.r2, q.r2], q' = [p.r1, q.r1, p.r3, q.r3]
+// The swaps are issued as inline asm: hipcc (ROCm 7.2) mis-compiles the
+// __builtin_amdgcn_permlane{16,32}_swap pair result when two of them feed a third (it adds the
+// first result to itself; caught by tests/hip_unit/wave_ops.hip).  The s_nop covers the
+// VALU-write -> permlane-swap-read wait states hipcc does not insert around asm statements.
+__device__ __forceinline__ float swap32_sum(float x, float y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+__device__ __forceinline__ float swap16_sum(float p, float q) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+    return p + q;
+}
+__device__ __forceinline__ float wave_sum4_to_rows(float v0, float v1, float v2, float v3) {
+    const float s02 = swap32_sum(v0, v2);  // lanes 0-31: v0 partials, 32-63: v2 partials
+    const float s13 = swap32_sum(v1, v3);
+    float r = swap16_sum(s02, s13);        // rows: v0, v1, v2, v3 (16 partials each)
+    r += dpp_f32<0xB1>(r);                 // quad_perm:[1,0,3,2]
+    r += dpp_f32<0x4E>(r);                 // quad_perm:[2,3,0,1]
+    r += dpp_f32<0x124>(r);                // row_ror:4
+    r += dpp_f32<0x128>(r);                // row_ror:8
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_sum_to_lane63(v), 63);
 }
@@ -136,6 +163,26 @@ __device__ __forceinline__ void get_rect(float px, float py, int max_radius, int
     y1 = imin_(gy, imax_(0, sat_int((py + max_radius + TILE - 1) / TILE)));
 }
 
+// Tiles a splat is binned into: the reference's 3-sigma square rect [x0,x1) x [y0,y1) (getRect)
+// intersected with the tiles its alpha-cutoff box (record quad 5) touches.  Pixel centres sit on
+// integer coordinates, tile t covers pixels [16 t, 16 t + 15].
+__device__ __forceinline__ void tight_tile_rect(const float4 box, int x0, int y0, int x1, int y1, int& tx0,
+                                                int& ty0, int& tx1, int& ty1) {
+    const int LIM = 1 << 20;
+    const int bx0 = imax_(-LIM, imin_(LIM, sat_int(floorf(box.x * (1.0f / TILE)))));
+    const int by0 = imax_(-LIM, imin_(LIM, sat_int(floorf(box.y * (1.0f / TILE)))));
+    const int bx1 = imax_(-LIM, imin_(LIM, sat_int(floorf(box.z * (1.0f / TILE))))) + 1;
+    const int by1 = imax_(-LIM, imin_(LIM, sat_int(floorf(box.w * (1.0f / TILE))))) + 1;
+    tx0 = imax_(x0, bx0);
+    ty0 = imax_(y0, by0);
+    tx1 = imax_(tx0, imin_(x1, bx1));
+    ty1 = imax_(ty0, imin_(y1, by1));
+    if (!(box.x <= box.z) || !(box.y <= box.w)) {  // empty box
+        tx1 = tx0;
+        ty1 = ty0;
+    }
+}
+
 constexpr float NEAR_N = 0.2f;    // auxiliary.h:37
 constexpr float FAR_N = 100.0f;   // auxiliary.h:38
 constexpr float FILTER_INV_SQUARE = 2.0f;  // auxiliary.h:39
@@ -170,7 +217,8 @@ __device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float 
     if (e.depth < NEAR_N) return false;
     const float power = -0.5f * rho;
     if (power > 0.0f) return false;
-    e.G = expf(power);
+    // exp(power) as one v_exp_f32: power in [-5.6, 0] for anything that can pass, error ~3e-7 relative
+    e.G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
     e.alpha = fminf(0.99f, opa * e.G);
     if (e.alpha < 1.0f / 255.0f) return false;
     return true;

@@ -9,8 +9,16 @@
 namespace g4s {
 
 constexpr int TILE = 16;           // tile edge in pixels (part of the output definition, auxiliary.h:66-76)
-constexpr int REC_FLOATS = 20;     // per-Gaussian splat record, 80 B = 5 x float4
-constexpr int GRAD_FLOATS = 18;    // per-instance gradient record (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
+constexpr int REC_FLOATS = 24;     // per-Gaussian splat record, 96 B = 6 x float4 (layout below)
+constexpr int REC_QUADS = REC_FLOATS / 4;
+constexpr int GRAD_FLOATS = 18;    // gradient terms per instance (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
+constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 16-byte aligned; last two unused)
+// Splat record (written by the forward preprocess, read by emit / blend / backward):
+//   q0 = (centre.x, centre.y, bits(inst_off), bits(tight tile count))
+//   q1 = (normal.xyz (view space, flipped towards the camera), opacity)
+//   q2 = (Tu.x, Tu.y, Tu.z, Tv.x)   q3 = (Tv.y, Tv.z, Tw.x, Tw.y)   q4 = (Tw.z, r, g, b)
+//   q5 = conservative pixel bounding box (x0, y0, x1, y1) of the region where this splat can pass
+//        the 1/255 alpha test (empty: x0 > x1)
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 constexpr int SORT_CHUNK = 2048;   // keys per wave-private radix chunk
 // Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
@@ -90,6 +98,7 @@ inline char* align_ptr(char* p) { return (char*)align_up((size_t)p); }
 
 struct PreprocessArgs {
     int P, D, M, W, H, tiles_x, tiles_y;
+    uint32_t* ref_total;  // += sum of the reference's tiles_touched (3-sigma square rect) = num_rendered
     const float *means3D, *scales, *rotations, *opacities, *shs, *transMat_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;

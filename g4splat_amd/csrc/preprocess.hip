@@ -60,6 +60,46 @@ __device__ __forceinline__ bool compute_aabb(const float* T, float cutoff, float
     return true;
 }
 
+// Conservative pixel-space bounding box of the region where a splat can reach alpha >= 1/255:
+//   alpha = min(0.99, opa * exp(-min(rho3d, rho2d) / 2)) >= 1/255  <=>  min(rho3d, rho2d) <= 2 ln(255 opa) =: thr
+// i.e. the union of the projected ellipse {rho3d <= thr} (compute_aabb's formula, forward.cu:119-147,
+// evaluated at cutoff^2 = thr instead of 9) and the low-pass disk {rho2d <= thr} around the 3-sigma
+// centre.  thr is inflated by 0.1 % + 1e-3 and the box by one pixel + 0.1 %, so no float rounding in
+// the per-pixel evaluation can put a passing pixel outside it; where the cutoff conic is not an
+// ellipse (the disk crosses the camera plane) the box is unbounded.  The kernels only use the box
+// to SKIP work (tiles at emit, 8x8 quadrants in the blend loops); it never changes a result.
+__device__ __forceinline__ void alpha_cutoff_box(const float* T, float cx, float cy, float opa, float4& box) {
+    box = make_float4(1.0f, 1.0f, 0.0f, 0.0f);  // empty
+    const float thr = 2.0f * logf(255.0f * opa);
+    if (!(thr > 0.0f)) return;  // can never pass the alpha test (also catches NaN)
+    const float t = thr * 1.001f + 1e-3f;
+    const float BIG = 3.0e38f;
+    float lo_x = -BIG, lo_y = -BIG, hi_x = BIG, hi_y = BIG;
+    const float* Tu = T;
+    const float* Tv = T + 3;
+    const float* Tw = T + 6;
+    const float d = t * (Tw[0] * Tw[0] + Tw[1] * Tw[1]) - Tw[2] * Tw[2];
+    if (d < 0.0f) {
+        const float f0 = t / d, f2 = -1.0f / d;
+        const float ccx = f0 * (Tu[0] * Tw[0] + Tu[1] * Tw[1]) + f2 * Tu[2] * Tw[2];
+        const float ccy = f0 * (Tv[0] * Tw[0] + Tv[1] * Tw[1]) + f2 * Tv[2] * Tw[2];
+        const float hx = ccx * ccx - (f0 * (Tu[0] * Tu[0] + Tu[1] * Tu[1]) + f2 * Tu[2] * Tu[2]);
+        const float hy = ccy * ccy - (f0 * (Tv[0] * Tv[0] + Tv[1] * Tv[1]) + f2 * Tv[2] * Tv[2]);
+        const float ex = sqrtf(fmaxf(hx, 0.0f)), ey = sqrtf(fmaxf(hy, 0.0f));
+        const float r2 = sqrtf(0.5f * t);  // rho2d = 2 |d|^2 <= t
+        const float ax0 = fminf(ccx - ex, cx - r2), ax1 = fmaxf(ccx + ex, cx + r2);
+        const float ay0 = fminf(ccy - ey, cy - r2), ay1 = fmaxf(ccy + ey, cy + r2);
+        // any NaN / inf in the algebra above => keep the unbounded box
+        if (fabsf(ax0) < BIG && fabsf(ax1) < BIG && fabsf(ay0) < BIG && fabsf(ay1) < BIG) {
+            lo_x = ax0 - (1.0f + 1e-3f * fabsf(ax0));
+            hi_x = ax1 + (1.0f + 1e-3f * fabsf(ax1));
+            lo_y = ay0 - (1.0f + 1e-3f * fabsf(ay0));
+            hi_y = ay1 + (1.0f + 1e-3f * fabsf(ay1));
+        }
+    }
+    box = make_float4(lo_x, lo_y, hi_x, hi_y);
+}
+
 // Loads the 3*(deg+1)^2 active SH floats of Gaussian idx into registers.  vec16: the records are
 // 192 B ([16][3] floats) on a 16-byte aligned base, so they are fetched as 16-byte quads.
 __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int deg, bool vec16,
@@ -123,82 +163,100 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, F3 pos, F3 c
 }
 
 // K1: forward.cu:150-253.  Also seeds the depth sort (key = depth bits, CULLED_KEY if the
-// Gaussian emits nothing; payload = index).
+// Gaussian emits nothing; payload = index), computes the conservative alpha-cutoff bounding
+// box (record quad 5) and accumulates the reference's instance count (num_rendered).
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (idx >= a.P) return;
+    const bool in_range = idx < a.P;
     int radius_out = 0;
-    uint32_t touched = 0, key = CULLED_KEY, clamp_bits = 0;
+    uint32_t touched_ref = 0, touched = 0, key = CULLED_KEY, clamp_bits = 0;
     float rec[REC_FLOATS];
 #pragma unroll
     for (int i = 0; i < REC_FLOATS; i++) rec[i] = 0.0f;
+    rec[20] = 1.0f;  // empty box: x0 > x1
+    rec[21] = 1.0f;
 
-    const F3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-    const F3 p_view = xform_point_4x3(p, a.viewmatrix);
-    if (p_view.z > 0.2f) {  // in_frustum, auxiliary.h:184-209
-        float T[9];
-        F3 normal;
-        if (a.transMat_precomp == nullptr) {
-            float R[9];
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
-            const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
-            quat_to_rotmat(q, R);
-            compute_transmat(p, sc.x, sc.y, a.scale_modifier, R, a.projmatrix, a.W, a.H, T);
-            normal = xform_vec_4x3(mk3(R[6], R[7], R[8]), a.viewmatrix);
-        } else {
+    if (in_range) {
+        const F3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        const F3 p_view = xform_point_4x3(p, a.viewmatrix);
+        if (p_view.z > 0.2f) {  // in_frustum, auxiliary.h:184-209
+            float T[9];
+            F3 normal;
+            if (a.transMat_precomp == nullptr) {
+                float R[9];
+                const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+                const float2 sc = reinterpret_cast<const float2*>(a.scales)[idx];
+                quat_to_rotmat(q, R);
+                compute_transmat(p, sc.x, sc.y, a.scale_modifier, R, a.projmatrix, a.W, a.H, T);
+                normal = xform_vec_4x3(mk3(R[6], R[7], R[8]), a.viewmatrix);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 9; i++) T[i] = a.transMat_precomp[9 * (size_t)idx + i];
-            normal = mk3(0.0f, 0.0f, 1.0f);
-        }
-        // T is kept even if the Gaussian is culled below (forward.cu:197-200)
+                for (int i = 0; i < 9; i++) T[i] = a.transMat_precomp[9 * (size_t)idx + i];
+                normal = mk3(0.0f, 0.0f, 1.0f);
+            }
+            // T is kept even if the Gaussian is culled below (forward.cu:197-200)
 #pragma unroll
-        for (int i = 0; i < 9; i++) rec[8 + i] = T[i];
-        const float cosv = -((p_view.x * normal.x + p_view.y * normal.y) + p_view.z * normal.z);
-        if (cosv != 0) {
-            const float mult = cosv > 0 ? 1.0f : -1.0f;
-            normal = mk3(mult * normal.x, mult * normal.y, mult * normal.z);
-            float cx, cy, ex, ey;
-            if (compute_aabb(T, 3.0f, cx, cy, ex, ey)) {
-                const float radius = ceilf(fmaxf(ex, ey));
-                int x0, y0, x1, y1;
-                get_rect(cx, cy, sat_int(radius), a.tiles_x, a.tiles_y, x0, y0, x1, y1);
-                const int area = (x1 - x0) * (y1 - y0);
-                if (area != 0) {
-                    float rgb[3];
-                    if (a.colors_precomp == nullptr) {
-                        float sh[48];
-                        load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
-                        sh_to_rgb(a.D, sh, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), rgb, clamp_bits);
-                    } else {
-                        rgb[0] = a.colors_precomp[3 * (size_t)idx];
-                        rgb[1] = a.colors_precomp[3 * (size_t)idx + 1];
-                        rgb[2] = a.colors_precomp[3 * (size_t)idx + 2];
+            for (int i = 0; i < 9; i++) rec[8 + i] = T[i];
+            const float cosv = -((p_view.x * normal.x + p_view.y * normal.y) + p_view.z * normal.z);
+            if (cosv != 0) {
+                const float mult = cosv > 0 ? 1.0f : -1.0f;
+                normal = mk3(mult * normal.x, mult * normal.y, mult * normal.z);
+                float cx, cy, ex, ey;
+                if (compute_aabb(T, 3.0f, cx, cy, ex, ey)) {
+                    const float radius = ceilf(fmaxf(ex, ey));
+                    int x0, y0, x1, y1;
+                    get_rect(cx, cy, sat_int(radius), a.tiles_x, a.tiles_y, x0, y0, x1, y1);
+                    const int area = (x1 - x0) * (y1 - y0);
+                    if (area != 0) {
+                        float rgb[3];
+                        if (a.colors_precomp == nullptr) {
+                            float sh[48];
+                            load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+                            sh_to_rgb(a.D, sh, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), rgb, clamp_bits);
+                        } else {
+                            rgb[0] = a.colors_precomp[3 * (size_t)idx];
+                            rgb[1] = a.colors_precomp[3 * (size_t)idx + 1];
+                            rgb[2] = a.colors_precomp[3 * (size_t)idx + 2];
+                        }
+                        const float opa = a.opacities[idx];
+                        radius_out = sat_int(radius);
+                        touched_ref = (uint32_t)area;
+                        key = __float_as_uint(p_view.z);
+                        float4 box;
+                        alpha_cutoff_box(T, cx, cy, opa, box);
+                        int tx0, ty0, tx1, ty1;
+                        tight_tile_rect(box, x0, y0, x1, y1, tx0, ty0, tx1, ty1);
+                        touched = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
+                        rec[0] = cx;
+                        rec[1] = cy;
+                        rec[3] = __uint_as_float(touched);
+                        rec[4] = normal.x;
+                        rec[5] = normal.y;
+                        rec[6] = normal.z;
+                        rec[7] = opa;
+                        rec[17] = rgb[0];
+                        rec[18] = rgb[1];
+                        rec[19] = rgb[2];
+                        rec[20] = box.x;
+                        rec[21] = box.y;
+                        rec[22] = box.z;
+                        rec[23] = box.w;
                     }
-                    radius_out = sat_int(radius);
-                    touched = (uint32_t)area;
-                    key = __float_as_uint(p_view.z);
-                    rec[0] = cx;
-                    rec[1] = cy;
-                    rec[3] = __uint_as_float(touched);
-                    rec[4] = normal.x;
-                    rec[5] = normal.y;
-                    rec[6] = normal.z;
-                    rec[7] = a.opacities[idx];
-                    rec[17] = rgb[0];
-                    rec[18] = rgb[1];
-                    rec[19] = rgb[2];
                 }
             }
         }
-    }
-    float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * 5;
+        float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * REC_QUADS;
 #pragma unroll
-    for (int i = 0; i < 5; i++) out[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
-    a.clamped[idx] = (uint8_t)clamp_bits;
-    a.tiles_touched[idx] = touched;
-    a.radii[idx] = radius_out;
-    a.depth_keys[idx] = key;
-    a.gidx[idx] = (uint32_t)idx;
+        for (int i = 0; i < REC_QUADS; i++) out[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+        a.clamped[idx] = (uint8_t)clamp_bits;
+        a.tiles_touched[idx] = touched;
+        a.radii[idx] = radius_out;
+        a.depth_keys[idx] = key;
+        a.gidx[idx] = (uint32_t)idx;
+    }
+    // num_rendered of the reference = sum of its tiles_touched (integer atomics: order independent)
+    const uint32_t wsum = wave_sum_u32(touched_ref);
+    if (lane_id() == 0 && wsum) atomicAdd(a.ref_total, wsum);
 }
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
@@ -339,40 +397,59 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
     return dnormvdv(dir_orig, dL_ddir);
 }
 
-// K8: backward.cu:586-641 + compute_transmat_aabb :443-584.  First folds this Gaussian's
-// per-instance gradient records (written by the blend backward, one per (tile, Gaussian)
-// instance, contiguous at [inst_off, inst_off + count)) in a fixed order -- the
-// deterministic replacement of the reference's float atomics.
+// K8: backward.cu:586-641 + compute_transmat_aabb :443-584.
+//
+// Phase 1 folds every Gaussian's per-instance gradient records (written by the blend backward,
+// one per (tile, Gaussian) instance, contiguous at [inst_off, inst_off + count)) in a fixed order
+// -- the deterministic replacement of the reference's float atomics.  The block's 256 x 18
+// (Gaussian, term) sums are spread over the threads so that consecutive lanes read consecutive
+// floats of a record (coalesced 72-byte runs) and land in LDS.  Phase 2 is one thread per
+// Gaussian.  Every output element is written (zeros for invisible Gaussians).
+constexpr int K8_SUM_STRIDE = GRAD_FLOATS + 1;  // LDS row stride, odd => conflict-free column reads
+
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
-    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (idx >= a.P) return;
+    __shared__ float s_sum[256 * K8_SUM_STRIDE];
+    __shared__ uint32_t s_off[256], s_cnt[256];
+    const int t = (int)threadIdx.x;
+    const int idx = (int)(blockIdx.x * 256 + t);
+    const bool in_range = idx < a.P;
+    const bool visible = in_range && a.radii[idx] > 0;
+    const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)(in_range ? idx : 0) * REC_QUADS;
+    {
+        uint32_t off = 0, cnt = 0;
+        if (visible) {
+            const float4 q0 = rq[0];
+            off = __float_as_uint(q0.z);
+            cnt = __float_as_uint(q0.w);
+        }
+        s_off[t] = off;
+        s_cnt[t] = cnt;
+    }
+    __syncthreads();
+    for (int pi = t; pi < 256 * GRAD_FLOATS; pi += 256) {
+        const int gl = pi / GRAD_FLOATS, q = pi - gl * GRAD_FLOATS;
+        const uint32_t cnt = s_cnt[gl];
+        const float* src = a.grad_inst + (size_t)s_off[gl] * GRAD_STRIDE + q;
+        float acc = 0.0f;
+        for (uint32_t k = 0; k < cnt; k++) acc += src[(size_t)k * GRAD_STRIDE];
+        s_sum[gl * K8_SUM_STRIDE + q] = acc;
+    }
+    __syncthreads();
+    if (!in_range) return;
+
     float g[GRAD_FLOATS];
 #pragma unroll
-    for (int i = 0; i < GRAD_FLOATS; i++) g[i] = 0.0f;
+    for (int i = 0; i < GRAD_FLOATS; i++) g[i] = s_sum[t * K8_SUM_STRIDE + i];
+    // g: [0..2] colour, [3..5] normal, [6..14] T (Tu,Tv,Tw), [15..16] mean2D, [17] opacity
     float dmean3[3] = {0, 0, 0}, dscale[2] = {0, 0};
     float4 drot = make_float4(0, 0, 0, 0);
     float dmean2[3] = {0, 0, 0};
-    float dT_out[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool visible = a.radii[idx] > 0;
+    float dT_out[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) dT_out[i] = g[6 + i];
     float* dsh = a.M > 0 ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr;
 
     if (visible) {
-        const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)idx * 5;
-        const float4 q0 = rq[0];
-        const uint32_t inst_off = __float_as_uint(q0.z), count = __float_as_uint(q0.w);
-        const float2* gp = reinterpret_cast<const float2*>(a.grad_inst + (size_t)inst_off * GRAD_FLOATS);
-        for (uint32_t k = 0; k < count; k++) {
-#pragma unroll
-            for (int i = 0; i < GRAD_FLOATS / 2; i++) {
-                const float2 v = gp[(size_t)k * (GRAD_FLOATS / 2) + i];
-                g[2 * i] += v.x;
-                g[2 * i + 1] += v.y;
-            }
-        }
-        // g: [0..2] colour, [3..5] normal, [6..14] T (Tu,Tv,Tw), [15..16] mean2D, [17] opacity
-#pragma unroll
-        for (int i = 0; i < 9; i++) dT_out[i] = g[6 + i];
-
         const bool precomp = (a.scales == nullptr);
         const float4 q4 = rq[4];
         const float depth_T8 = q4.x;  // transMats[idx*9+8]
@@ -490,7 +567,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     }
 
     a.dL_dmean2D[3 * idx] = dmean2[0]; a.dL_dmean2D[3 * idx + 1] = dmean2[1]; a.dL_dmean2D[3 * idx + 2] = dmean2[2];
-    a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5];
+    if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5]; }
     a.dL_dopacity[idx] = g[17];
     a.dL_dcolor[3 * idx] = g[0]; a.dL_dcolor[3 * idx + 1] = g[1]; a.dL_dcolor[3 * idx + 2] = g[2];
     a.dL_dmean3D[3 * idx] = dmean3[0]; a.dL_dmean3D[3 * idx + 1] = dmean3[1]; a.dL_dmean3D[3 * idx + 2] = dmean3[2];

@@ -85,7 +85,7 @@ int g4s_rasterizer_forward(
     float* out_color, float* out_others, int* radii, int debug, void* stream);
 
 /* Bytes of transient workspace g4s_rasterizer_backward needs for a forward that
- * returned R (per-instance gradient records, 72 B each + alignment). */
+ * returned R (per-instance gradient records, 80 B each + alignment). */
 size_t g4s_rasterizer_backward_workspace(int P, int R);
 
 /*
@@ -98,7 +98,8 @@ size_t g4s_rasterizer_backward_workspace(int P, int R);
  *   workspace : >= g4s_rasterizer_backward_workspace(P,R) bytes, contents undefined
  *   outputs (all fully written, no pre-zeroing needed; rows of invisible Gaussians = 0):
  *     dL_dmean2D[P,3]  (densification surrogate, backward.cu:637-640; .z = 0)
- *     dL_dnormal[P,3], dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3],
+ *     dL_dnormal[P,3] (view-space normal gradient; may be NULL, the reference's binding never
+ *     returns it), dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3],
  *     dL_dtransMat[P,9], dL_dsh[P,M,3] (if M > 0), dL_dscale[P,2], dL_drot[P,4]
  * Deterministic (no floating-point atomics), unlike the reference.
  * Returns G4S_OK or a negative G4S_ERR_*.
@@ -139,7 +140,7 @@ int g4s_knn_mean_dist(int P, const float* points, float* meanDists, char* worksp
  * callbacks.  Not part of the drop-in surface. */
 typedef struct g4s_layout {
     /* geometry chunk */
-    size_t rec;          /* P x 20 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb */
+    size_t rec;          /* P x 24 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb, box */
     size_t clamped;      /* P x u8 (bit c = channel c clamped) */
     size_t depth_sorted; /* P x u32 Gaussian indices in (depth, index) order, culled ones last */
     size_t tiles_touched;/* P x u32 */

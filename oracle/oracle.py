@@ -151,6 +151,22 @@ class Oracle:
         return np.frombuffer(buf, dtype=dt).reshape(shape).copy()
 
 
+def instance_flags(o):
+    """uint8[R]: 1 where the (tile, Gaussian) instance of Oracle `o` has a pixel passing the alpha test."""
+    R = o._fw["R"]
+    flags = np.zeros((max(R, 1),), np.uint8)
+    lib().oracle_instance_flags(o._s, _ptr(flags))
+    return flags[:R]
+
+
+def instance_flags(o):
+    """uint8[R]: 1 where the (tile, Gaussian) instance of Oracle `o` has a pixel passing the alpha test."""
+    R = o._fw["R"]
+    flags = np.zeros((max(R, 1),), np.uint8)
+    lib().oracle_instance_flags(o._s, _ptr(flags))
+    return flags[:R]
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """dsr/rasterize_points.cu:235-254"""
     m = _f32(means3D)

@@ -889,3 +889,66 @@ void oracle_knn(int P, const float *points, float *meanDists) {
         meanDists[i] = (best[0] + best[1] + best[2]) / 3.0f;
     }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Workload statistics (not part of the restatement): how many (pixel, splat) pairs of the
+ * tile lists are evaluated / pass the alpha test / are blended, at pixel, 8x8-quadrant and
+ * tile granularity.  Used to size the wave-level skipping of the HIP kernels. */
+void oracle_pair_stats(const OracleState *s, double *out /*8*/) {
+    const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+    const size_t N = (size_t)W * H;
+    double pairs = 0, pass = 0, blended = 0, quad_any_pass = 0, quad_total = 0, tile_any_pass = 0, tile_total = 0, quad_any_blend = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+:pairs,pass,blended,quad_any_pass,quad_total,tile_any_pass,tile_total,quad_any_blend)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (uint32_t i = r0; i < r1; i++) {
+            uint32_t id = s->point_list[i];
+            const float *no = s->normal_opacity + 4 * (size_t)id;
+            int tile_any = 0;
+            for (int q = 0; q < 4; q++) {
+                int qa = 0, qb = 0;
+                for (int l = 0; l < 64; l++) {
+                    int px = tx * 16 + (q & 1) * 8 + (l & 7), py = ty * 16 + (q >> 1) * 8 + (l >> 3);
+                    if (px >= W || py >= H) continue;
+                    size_t pix = (size_t)W * py + px;
+                    pairs += 1;
+                    PairEval e;
+                    if (!eval_pair((float)px, (float)py, s->means2D + 2 * (size_t)id, s->transMat + 9 * (size_t)id, no[3], &e)) continue;
+                    pass += 1; qa = 1;
+                    if ((i - r0) < s->n_contrib[pix]) { blended += 1; qb = 1; }
+                }
+                quad_total += 1; quad_any_pass += qa; quad_any_blend += qb; tile_any |= qb;
+            }
+            tile_total += 1; tile_any_pass += tile_any;
+        }
+    }
+    (void)N;
+    out[0] = pairs; out[1] = pass; out[2] = blended; out[3] = quad_total; out[4] = quad_any_pass;
+    out[5] = quad_any_blend; out[6] = tile_total; out[7] = tile_any_pass;
+}
+
+/* Per-instance flag (test infrastructure): 1 if at least one pixel of the instance's tile passes
+ * the per-pixel tests of eval_pair for that splat (p.z != 0, depth >= near, alpha >= 1/255),
+ * i.e. the instance is NOT provably dead.  The HIP path may drop exactly the instances whose flag
+ * is 0 (alpha-cutoff tile culling); tests assert it never drops a flagged one. */
+void oracle_instance_flags(const OracleState *s, uint8_t *flags /*R*/) {
+    const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (uint32_t i = r0; i < r1; i++) {
+            uint32_t id = s->point_list[i];
+            const float *no = s->normal_opacity + 4 * (size_t)id;
+            uint8_t f = 0;
+            for (int l = 0; l < 256 && !f; l++) {
+                int px = tx * 16 + (l & 15), py = ty * 16 + (l >> 4);
+                if (px >= W || py >= H) continue;
+                PairEval e;
+                if (eval_pair((float)px, (float)py, s->means2D + 2 * (size_t)id, s->transMat + 9 * (size_t)id, no[3], &e)) f = 1;
+            }
+            flags[i] = f;
+        }
+    }
+}

@@ -1,0 +1,40 @@
+// Standalone unit check of the wave64 primitives in g4s_device.h (run on the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tests/hip_unit/wave_ops.hip -o /tmp/wave_ops && /tmp/wave_ops
+#include <cstdio>
+#include <vector>
+#include "../../g4splat_amd/csrc/g4s_device.h"
+using namespace g4s;
+
+__global__ void k_sum4(const float* in, float* out) {
+    const int l = threadIdx.x;
+    out[l] = wave_sum4_to_rows(in[l], in[64 + l], in[128 + l], in[192 + l]);
+}
+__global__ void k_sum63(const float* in, float* out) { out[threadIdx.x] = wave_sum_to_lane63(in[threadIdx.x]); }
+__global__ void k_swap32(const float* in, float* out) { out[threadIdx.x] = swap32_sum(in[threadIdx.x], in[64 + threadIdx.x]); }
+__global__ void k_swap16(const float* in, float* out) { out[threadIdx.x] = swap16_sum(in[threadIdx.x], in[64 + threadIdx.x]); }
+
+int main() {
+    std::vector<float> h(256);
+    for (int v = 0; v < 4; v++) for (int l = 0; l < 64; l++) h[v * 64 + l] = (float)((v + 1) * 1000 + l);  // exact in f32
+    float *din, *dout;
+    hipMalloc(&din, 1024); hipMalloc(&dout, 256);
+    hipMemcpy(din, h.data(), 1024, hipMemcpyHostToDevice);
+    std::vector<float> o(64);
+    int bad = 0;
+    double want[4];
+    for (int v = 0; v < 4; v++) { want[v] = 0; for (int l = 0; l < 64; l++) want[v] += h[v * 64 + l]; }
+    hipLaunchKernelGGL(k_sum4, dim3(1), dim3(64), 0, 0, din, dout);
+    hipMemcpy(o.data(), dout, 256, hipMemcpyDeviceToHost);
+    for (int l = 0; l < 64; l++) if (o[l] != (float)want[l >> 4]) { bad++; if (bad < 8) printf("sum4 lane %d got %f want %f\n", l, o[l], want[l >> 4]); }
+    hipLaunchKernelGGL(k_sum63, dim3(1), dim3(64), 0, 0, din, dout);
+    hipMemcpy(o.data(), dout, 256, hipMemcpyDeviceToHost);
+    if (o[63] != (float)want[0]) { bad++; printf("sum63 got %f want %f\n", o[63], want[0]); }
+    hipLaunchKernelGGL(k_swap32, dim3(1), dim3(64), 0, 0, din, dout);
+    hipMemcpy(o.data(), dout, 256, hipMemcpyDeviceToHost);
+    for (int l = 0; l < 64; l++) { float w = l < 32 ? h[l] + h[l + 32] : h[64 + l - 32] + h[64 + l]; if (o[l] != w) { bad++; if (bad < 16) printf("swap32 lane %d got %f want %f\n", l, o[l], w); } }
+    hipLaunchKernelGGL(k_swap16, dim3(1), dim3(64), 0, 0, din, dout);
+    hipMemcpy(o.data(), dout, 256, hipMemcpyDeviceToHost);
+    for (int l = 0; l < 64; l++) { int r = l >> 4, c = l & 15; float w = (r == 0) ? h[c] + h[16 + c] : (r == 1) ? h[64 + c] + h[64 + 16 + c] : (r == 2) ? h[32 + c] + h[48 + c] : h[64 + 32 + c] + h[64 + 48 + c]; if (o[l] != w) { bad++; if (bad < 24) printf("swap16 lane %d got %f want %f\n", l, o[l], w); } }
+    printf(bad ? "FAILED (%d)\n" : "wave_ops OK\n", bad);
+    return bad != 0;
+}
