@@ -218,8 +218,7 @@ extern "C" int g4s_rasterizer_forward(
         pa.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16));
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
         pa.depth_keys = keys_a; pa.gidx = vals_a;
-        pa.ref_total = d_total + 1;
-        HIP_TRY(hipMemsetAsync(d_total, 0, 8, stream));
+        pa.ref_block_sums = (uint32_t*)(geom + GL.ref_block_sums);
         { ProfScope ps(PF_PREPROCESS_FWD, stream); launch_preprocess_fwd(pa, stream); }
         CHECK_LAUNCH("preprocess_fwd");
 
@@ -232,7 +231,8 @@ extern "C" int g4s_rasterizer_forward(
         const uint32_t* gidx_sorted = cur ? vals_b : vals_a;
 
         { ProfScope ps(PF_COUNT_SCAN, stream);
-          launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, d_total, GL.nblocks, stream); }
+          launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs,
+                            (const uint32_t*)(geom + GL.ref_block_sums), d_total, GL.nblocks, stream); }
         CHECK_LAUNCH("count scan");
 
         // the one host synchronisation of the forward (rasterizer_impl.cu:281-282)

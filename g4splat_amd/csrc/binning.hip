@@ -179,34 +179,48 @@ __global__ void __launch_bounds__(256) count_block_sums_kernel(int P, const uint
 // Single block: exclusive scan of the block sums, grand total to *total.
 __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, const uint32_t* __restrict__ block_sums,
                                                                uint32_t* __restrict__ block_offs,
+                                                               const uint32_t* __restrict__ ref_block_sums,
                                                                uint32_t* __restrict__ total) {
-    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t wsum[16], rsum[16];
     const int t = (int)threadIdx.x;
     const int seg = (nblocks + 1023) / 1024;
     const int b = imin_(nblocks, t * seg), e = imin_(nblocks, b + seg);
-    uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += block_sums[i];
+    uint32_t sum = 0, ref = 0;
+    for (int i = b; i < e; i++) {
+        sum += block_sums[i];
+        ref += ref_block_sums[i];
+    }
     const uint32_t inc = wave_incl_scan_u32(sum);
-    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    const uint32_t rinc = wave_incl_scan_u32(ref);
+    if ((t & 63) == 63) {
+        wsum[t >> 6] = inc;
+        rsum[t >> 6] = rinc;
+    }
     __syncthreads();
-    uint32_t base = 0, all = 0;
+    uint32_t base = 0, all = 0, rall = 0;
     for (int w = 0; w < 16; w++) {
         if (w < (t >> 6)) base += wsum[w];
         all += wsum[w];
+        rall += rsum[w];
     }
     uint32_t run = base + inc - sum;
     for (int i = b; i < e; i++) {
         block_offs[i] = run;
         run += block_sums[i];
     }
-    if (t == 0) *total = all;
+    if (t == 0) {
+        total[0] = all;
+        total[1] = rall;
+    }
 }
 
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
-                       uint32_t* block_offs, uint32_t* total, int nblocks, hipStream_t s) {
+                       uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
+                       hipStream_t s) {
     hipLaunchKernelGGL(count_block_sums_kernel, dim3(nblocks), dim3(256), 0, s, P, gidx_sorted, tiles_touched,
                        block_sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs, total);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs,
+                       ref_block_sums, total);
 }
 
 // Load-balanced expansion: a block owns 256 consecutive depth ranks; its output range is

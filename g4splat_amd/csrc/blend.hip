@@ -67,41 +67,51 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
         }
         __syncthreads();
         if (__all(done)) continue;  // this quadrant is finished; keep taking part in the staging
-        for (int j = 0; j < m; j++) {
+        // Each group of 64 staged entries is first filtered against this wave's quadrant with one
+        // box test per lane + a ballot; only entries whose alpha-cutoff box touches the quadrant are
+        // visited (scalar bit scan), so a rejected entry costs ~1/64 of a loop iteration.
+        for (int g0 = 0; g0 < m; g0 += 64) {
+            const int jl = g0 + lane;
+            const bool rel = jl < m && !quad_misses_box(s_rec[5][jl < FWD_BATCH ? jl : 0], qxf, qyf);
+            uint64_t todo = __ballot(rel);
+            while (todo) {
+                if (__all(done)) break;
+                const int j = g0 + (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                if (done) continue;
+                // `contributor` of the reference = 1-based list position (forward.cu:349)
+                const uint32_t contributor = (uint32_t)(b0 + j + 1);
+                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
+                PairEval e;
+                if (!eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e))
+                    continue;
+                const float alpha = e.alpha, depth = e.depth;
+                const float test_T = T * (1 - alpha);
+                if (test_T < 0.0001f) {
+                    done = true;
+                    continue;
+                }
+                const float w = alpha * T;
+                const float A = 1 - T;
+                const float md = mscale * (1 - NEAR_N * __builtin_amdgcn_rcpf(depth));
+                distortion += (md * md * A + M2 - 2 * md * M1) * w;
+                Dd = fmaf(depth, w, Dd);
+                M1 = fmaf(md, w, M1);
+                M2 = fmaf(md * md, w, M2);
+                if (T > 0.5f) {
+                    median_depth = depth;
+                    median_contributor = contributor;
+                }
+                N0 = fmaf(q1.x, w, N0);
+                N1 = fmaf(q1.y, w, N1);
+                N2 = fmaf(q1.z, w, N2);
+                C0 = fmaf(q4.y, w, C0);
+                C1 = fmaf(q4.z, w, C1);
+                C2 = fmaf(q4.w, w, C2);
+                T = test_T;
+                last_contributor = contributor;
+            }
             if (__all(done)) break;
-            if (quad_misses_box(s_rec[5][j], qxf, qyf)) continue;  // wave-uniform
-            if (done) continue;
-            // `contributor` of the reference = 1-based list position (forward.cu:349)
-            const uint32_t contributor = (uint32_t)(b0 + j + 1);
-            const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-            PairEval e;
-            if (!eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e))
-                continue;
-            const float alpha = e.alpha, depth = e.depth;
-            const float test_T = T * (1 - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
-            }
-            const float w = alpha * T;
-            const float A = 1 - T;
-            const float md = mscale * (1 - NEAR_N * __builtin_amdgcn_rcpf(depth));
-            distortion += (md * md * A + M2 - 2 * md * M1) * w;
-            Dd = fmaf(depth, w, Dd);
-            M1 = fmaf(md, w, M1);
-            M2 = fmaf(md * md, w, M2);
-            if (T > 0.5f) {
-                median_depth = depth;
-                median_contributor = contributor;
-            }
-            N0 = fmaf(q1.x, w, N0);
-            N1 = fmaf(q1.y, w, N1);
-            N2 = fmaf(q1.z, w, N2);
-            C0 = fmaf(q4.y, w, C0);
-            C1 = fmaf(q4.z, w, C1);
-            C2 = fmaf(q4.w, w, C2);
-            T = test_T;
-            last_contributor = contributor;
         }
     }
     if (inside) {
@@ -144,7 +154,7 @@ struct BwdPixel {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[REC_QUADS][BWD_BATCH];
+    __shared__ float4 s_rec[REC_QUADS - 1][BWD_BATCH];  // the box quad is consumed at staging time
     __shared__ uint32_t s_slot[BWD_BATCH];
 
     const int tile = (int)blockIdx.x;
@@ -193,8 +203,13 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
     const bool row_writer = (lane & 15) == 15;
     const int row = lane >> 4;
 
-    // list positions >= max(last_contributor) over the tile contribute nothing: zero records
-    const int n_live = (int)wave_max_u32(max_last);
+    // per-quadrant live bounds (wave-uniform): list positions >= the quadrant's max last_contributor
+    // cannot contribute in that quadrant; >= the tile's maximum nowhere
+    uint32_t qlive[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) qlive[q] = wave_max_u32(p[q].last_c);
+    const int n_live = (int)max(max(qlive[0], qlive[1]), max(qlive[2], qlive[3]));
+    (void)max_last;
     for (int j = n_live + lane; j < n; j += 64) {
         const uint64_t e = a.entries[r0 + j];
         const uint32_t slot = __float_as_uint(a.rec[(size_t)entry_idx(e) * REC_FLOATS + 2]) + entry_k(e);
@@ -207,33 +222,47 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
     for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
         const int m = imin_(BWD_BATCH, hi);
         __syncthreads();
+        uint32_t qmask = 0;  // bit q: quadrant q can be touched by the entry this lane staged
         if (lane < m) {
-            const uint64_t e = a.entries[r0 + (uint32_t)(hi - 1 - lane)];
+            const uint32_t pos_l = (uint32_t)(hi - 1 - lane);
+            const uint64_t e = a.entries[r0 + pos_l];
             const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
-            const float4 q0 = r[0];
+            const float4 q0 = r[0], box = r[5];
             s_rec[0][lane] = q0;
 #pragma unroll
-            for (int i = 1; i < REC_QUADS; i++) s_rec[i][lane] = r[i];
-            s_slot[lane] = __float_as_uint(q0.z) + entry_k(e);
+            for (int i = 1; i < REC_QUADS - 1; i++) s_rec[i][lane] = r[i];
+            const uint32_t slot = __float_as_uint(q0.z) + entry_k(e);
+            s_slot[lane] = slot;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (pos_l < qlive[q] && !quad_misses_box(box, (float)(tx0 + (q & 1) * 8), (float)(ty0 + (q >> 1) * 8)))
+                    qmask |= 1u << q;
+            if (qmask == 0) {  // dead for every quadrant: its record is zero, written right here
+                float4* dst = reinterpret_cast<float4*>(a.grad_inst + (size_t)slot * GRAD_STRIDE);
+#pragma unroll
+                for (int i = 0; i < GRAD_STRIDE / 4; i++) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
 
-        for (int j = 0; j < m; j++) {
+        uint64_t todo = __ballot(qmask != 0);
+        while (todo) {
+            const int j = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)qmask, j);  // wave-uniform
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-            const float4 box = s_rec[5][j];
             float g[GRAD_STRIDE];
 #pragma unroll
             for (int i = 0; i < GRAD_STRIDE; i++) g[i] = 0.0f;
             bool any_active = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (quad_misses_box(box, (float)(tx0 + (q & 1) * 8), (float)(ty0 + (q >> 1) * 8))) continue;  // uniform
+                if (!((qm >> q) & 1u)) continue;  // scalar branch
                 BwdPixel& x = p[q];
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
                 bool act = pos < x.last_c;
-                if (!__any(act)) continue;
                 if (act)
                     act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
                 if (!__any(act)) continue;

@@ -36,7 +36,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // (the reference's GeometryState/BinningState/ImageState, rasterizer_impl.h:21-73).
 struct GeomLayout {
     size_t rec, clamped, tiles_touched, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
-        block_sums, block_offs, total, bytes;
+        block_sums, block_offs, ref_block_sums, total, bytes;
     int nchunks;   // radix chunks over P
     int nblocks;   // 256-wide blocks over P
 };
@@ -66,6 +66,7 @@ inline GeomLayout geom_layout(size_t P) {
     L.bin_total = take(256 * 4);
     L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.ref_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.total = take(256);
     L.bytes = o + 256;  // slack for aligning the chunk base
     return L;
@@ -98,7 +99,7 @@ inline char* align_ptr(char* p) { return (char*)align_up((size_t)p); }
 
 struct PreprocessArgs {
     int P, D, M, W, H, tiles_x, tiles_y;
-    uint32_t* ref_total;  // += sum of the reference's tiles_touched (3-sigma square rect) = num_rendered
+    uint32_t* ref_block_sums;  // per 256-Gaussian block: sum of the reference's tiles_touched (3-sigma rect)
     const float *means3D, *scales, *rotations, *opacities, *shs, *transMat_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;
@@ -122,8 +123,10 @@ int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_
                         uint32_t* bin_total, int nchunks, hipStream_t s);
 
 // Exclusive scan (in depth order) of tiles_touched; total written to *total (device).
+// total[0] = instances binned, total[1] = sum of ref_block_sums (the reference's num_rendered).
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
-                       uint32_t* block_offs, uint32_t* total, int nblocks, hipStream_t s);
+                       uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
+                       hipStream_t s);
 void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,
                  const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
                  hipStream_t s);
