@@ -277,9 +277,12 @@ extern "C" int g4s_rasterizer_forward(
         (void)binning_buffer(binning_ctx, 0);
     }
 
+    uint32_t* tile_order = (uint32_t*)(img + IL.tile_order);
+    launch_tile_order(tiles, ranges, tile_order, stream);
+    CHECK_LAUNCH("tile order");
     BlendFwdArgs ba{};
     ba.W = width; ba.H = height; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y;
-    ba.ranges = ranges; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
+    ba.ranges = ranges; ba.tile_order = tile_order; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
     if (getenv("G4S_SKIP_BLEND")) return R;  // bring-up aid: leave the binning state for inspection
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
@@ -333,6 +336,7 @@ extern "C" int g4s_rasterizer_backward(
         BlendBwdArgs bb{};
         bb.W = width; bb.H = height; bb.tiles_x = tiles_x; bb.tiles_y = tiles_y;
         bb.ranges = (const uint32_t*)(img + IL.ranges);
+        bb.tile_order = (const uint32_t*)(img + IL.tile_order);
         bb.entries = (const uint64_t*)(bin + ((passes & 1) ? BL.ent_b : BL.ent_a));
         bb.rec = rec; bb.bg = background;
         bb.final_T = (const float*)(img + IL.final_T);

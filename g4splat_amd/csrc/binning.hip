@@ -305,6 +305,42 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int R, const uint64_t*
     if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
 }
 
+// Processing order of the tiles: longest instance list first (LPT scheduling).  A tile is one
+// workgroup of the blend kernels and list lengths are very uneven, so dispatching the heavy tiles
+// first shortens the tail.  Single block: bucket histogram (descending) in LDS, scan, scatter; the
+// order inside a bucket is arbitrary (it cannot change any result, tiles are independent).
+constexpr int ORDER_BUCKETS = 2048;
+__global__ void __launch_bounds__(1024) tile_order_kernel(int tiles, const uint32_t* __restrict__ ranges,
+                                                          uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[ORDER_BUCKETS];
+    __shared__ uint32_t wsum[16];
+    const int t = (int)threadIdx.x;
+    for (int i = t; i < ORDER_BUCKETS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    auto bucket = [](uint32_t n) {  // descending: long lists -> small bucket index
+        const uint32_t b = n >> 2;
+        return (uint32_t)(ORDER_BUCKETS - 1) - (b < (uint32_t)(ORDER_BUCKETS - 1) ? b : (uint32_t)(ORDER_BUCKETS - 1));
+    };
+    for (int i = t; i < tiles; i += 1024) atomicAdd(&hist[bucket(ranges[2 * i + 1] - ranges[2 * i])], 1u);
+    __syncthreads();
+    // exclusive scan of the 2048 buckets: two per thread
+    const uint32_t h0 = hist[2 * t], h1 = hist[2 * t + 1];
+    const uint32_t inc = wave_incl_scan_u32(h0 + h1);
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (t >> 6); w++) base += wsum[w];
+    const uint32_t ex = base + inc - (h0 + h1);
+    __syncthreads();
+    hist[2 * t] = ex;
+    hist[2 * t + 1] = ex + h0;
+    __syncthreads();
+    for (int i = t; i < tiles; i += 1024) order[atomicAdd(&hist[bucket(ranges[2 * i + 1] - ranges[2 * i])], 1u)] = (uint32_t)i;
+}
+void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, ranges, tile_order);
+}
+
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s) {
     if (R <= 0) return;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, entries, ranges);

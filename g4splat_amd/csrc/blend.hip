@@ -35,7 +35,7 @@ constexpr int FWD_BATCH = 256;
 
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[REC_QUADS][FWD_BATCH];
-    const int tile = (int)blockIdx.x;
+    const int tile = (int)a.tile_order[blockIdx.x];
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int qx = tile_x * TILE + (wv & 1) * 8, qy = tile_y * TILE + (wv >> 1) * 8;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[REC_QUADS - 1][BWD_BATCH];  // the box quad is consumed at staging time
     __shared__ uint32_t s_slot[BWD_BATCH];
 
-    const int tile = (int)blockIdx.x;
+    const int tile = (int)a.tile_order[blockIdx.x];
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int lane = (int)threadIdx.x;
     const size_t N = (size_t)a.W * a.H;

@@ -45,7 +45,7 @@ struct BinLayout {
     int nchunks;
 };
 struct ImgLayout {
-    size_t ranges, final_T, n_contrib, bytes;
+    size_t ranges, final_T, n_contrib, tile_order, bytes;
 };
 
 inline GeomLayout geom_layout(size_t P) {
@@ -90,6 +90,7 @@ inline ImgLayout img_layout(size_t N, size_t tiles) {
     L.ranges = take(tiles * 8);
     L.final_T = take(N * 3 * 4);
     L.n_contrib = take(N * 2 * 4);
+    L.tile_order = take(tiles * 4);
     L.bytes = o + 256;
     return L;
 }
@@ -131,10 +132,13 @@ void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, c
                  const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
                  hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s);
+// Longest-list-first processing order of the tiles (work balance of the blend kernels).
+void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s);
 
 struct BlendFwdArgs {
     int W, H, tiles_x, tiles_y;
     const uint32_t* ranges;
+    const uint32_t* tile_order;
     const uint64_t* entries;
     const float* rec;
     const float* bg;
@@ -148,6 +152,7 @@ void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 struct BlendBwdArgs {
     int W, H, tiles_x, tiles_y;
     const uint32_t* ranges;
+    const uint32_t* tile_order;
     const uint64_t* entries;
     const float* rec;
     const float* bg;
