@@ -329,6 +329,9 @@ extern "C" int g4s_rasterizer_backward(
     if (radii == nullptr) radii = (const int*)(geom + GL.internal_radii);
     float* grad_inst = (float*)align_ptr(workspace);
 
+    // dL_dsh is mostly zero rows (invisible Gaussians): fill it once at memset speed, K8 only writes
+    // the visible rows.  Issued ahead of the (VALU-bound) blend backward.
+    if (M > 0) HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * M * 3 * sizeof(float), stream));
     if (R > 0) {
         char* bin = align_ptr(binning_buffer);
         const int tile_bits = (int)higher_msb((uint32_t)tiles);
@@ -358,6 +361,7 @@ extern "C" int g4s_rasterizer_backward(
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
     pb.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
+    pb.dbg_skip = getenv("G4S_K8_SKIP") ? atoi(getenv("G4S_K8_SKIP")) : 0;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dtransMat = dL_dtransMat; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
     pb.dL_drot = dL_drot;

@@ -173,6 +173,7 @@ struct PreprocessBwdArgs {
     const uint8_t* clamped;
     const float* grad_inst;
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
+    int dbg_skip;   // bring-up/experiments only (G4S_K8_SKIP): 1 = skip fold, 2 = skip SH, 4 = skip small outputs
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
         *dL_drot;
 };

@@ -430,20 +430,80 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         s_cnt[t] = cnt;
     }
     __syncthreads();
-    for (int pi = t; pi < 256 * GRAD_FLOATS; pi += 256) {
-        const int gl = pi / GRAD_FLOATS, q = pi - gl * GRAD_FLOATS;
-        const uint32_t cnt = s_cnt[gl];
-        const float* src = a.grad_inst + (size_t)s_off[gl] * GRAD_STRIDE + q;
-        // eight independent loads in flight per thread; the summation order (k ascending) is fixed
-        float acc = 0.0f;
-        for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
-            float v[8];
+    // Fold, wave-cooperative: every wave walks its own 64 Gaussians' visible members (ballot +
+    // scalar bit scan), four at a time.  For one Gaussian the 64 lanes read 16 records x 4 quads
+    // (terms 0..15) per step -- one coalesced 16-byte load per lane covers a whole typical run --
+    // and a float2 per record for terms 16..17; the partial sums are combined with DPP row rotates
+    // and two cross-row exchanges in a fixed order.  A Gaussian with hundreds of instances costs
+    // cnt/16 steps of one wave instead of serialising a single thread.
+    if (!(a.dbg_skip & 1)) {
+        const int lane = lane_id();
+        const int wbase = (t >> 6) * 64;  // first local Gaussian of this wave
+        const uint32_t my_cnt = s_cnt[t], my_off = s_off[t];
+        uint64_t vis = __ballot(my_cnt != 0);
+        const int kk = lane >> 2, c = lane & 3;
+        while (vis) {
+            int jj[4];
+            uint32_t cn[4], of[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (k0 + u < cnt) ? src[(size_t)(k0 + u) * GRAD_STRIDE] : 0.0f;
+            for (int u = 0; u < 4; u++) {
+                jj[u] = vis ? (int)__builtin_ctzll(vis) : -1;
+                if (vis) vis &= vis - 1;
+                cn[u] = jj[u] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, jj[u] < 0 ? 0 : jj[u]) : 0u;
+                of[u] = jj[u] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)my_off, jj[u] < 0 ? 0 : jj[u]) : 0u;
+            }
+            float4 accA[4];
+            float2 accB[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc += v[u];
+            for (int u = 0; u < 4; u++) {
+                const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
+                const float2* base2 = reinterpret_cast<const float2*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
+                float4 sA = make_float4(0.f, 0.f, 0.f, 0.f);
+                float2 sB = make_float2(0.f, 0.f);
+                for (uint32_t k0 = 0; k0 < cn[u]; k0 += 64) {
+                    // terms 0..15: four sub-steps of 16 records x 4 quads
+#pragma unroll
+                    for (int sstep = 0; sstep < 4; sstep++) {
+                        const uint32_t k = k0 + 16 * sstep + kk;
+                        if (k0 + 16 * sstep < cn[u]) {  // uniform
+                            const float4 x = base4[(size_t)(k < cn[u] ? k : 0) * (GRAD_STRIDE / 4) + c];
+                            const float msk = k < cn[u] ? 1.0f : 0.0f;
+                            sA.x += msk * x.x; sA.y += msk * x.y; sA.z += msk * x.z; sA.w += msk * x.w;
+                        }
+                    }
+                    // terms 16..17: one record per lane
+                    const uint32_t kb = k0 + lane;
+                    const float2 y = base2[(size_t)(kb < cn[u] ? kb : 0) * (GRAD_STRIDE / 2) + 8];
+                    const float mb = kb < cn[u] ? 1.0f : 0.0f;
+                    sB.x += mb * y.x; sB.y += mb * y.y;
+                }
+                accA[u] = sA;
+                accB[u] = sB;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (jj[u] < 0) continue;  // uniform
+                float4 sA = accA[u];
+                float2 sB = accB[u];
+                // over kk = lane >> 2 (16 values): rotate by 4 and 8 lanes inside each row of 16, then rows
+                sA.x += dpp_f32<0x124>(sA.x); sA.y += dpp_f32<0x124>(sA.y); sA.z += dpp_f32<0x124>(sA.z); sA.w += dpp_f32<0x124>(sA.w);
+                sA.x += dpp_f32<0x128>(sA.x); sA.y += dpp_f32<0x128>(sA.y); sA.z += dpp_f32<0x128>(sA.z); sA.w += dpp_f32<0x128>(sA.w);
+                sA.x += __shfl_xor(sA.x, 16, 64); sA.y += __shfl_xor(sA.y, 16, 64); sA.z += __shfl_xor(sA.z, 16, 64); sA.w += __shfl_xor(sA.w, 16, 64);
+                sA.x += __shfl_xor(sA.x, 32, 64); sA.y += __shfl_xor(sA.y, 32, 64); sA.z += __shfl_xor(sA.z, 32, 64); sA.w += __shfl_xor(sA.w, 32, 64);
+                sB.x = wave_sum_to_lane63(sB.x);
+                sB.y = wave_sum_to_lane63(sB.y);
+                float* dst = s_sum + (wbase + jj[u]) * K8_SUM_STRIDE;
+                if (lane < 4) {  // kk == 0, c = lane: terms 4c..4c+3
+                    dst[4 * lane] = sA.x; dst[4 * lane + 1] = sA.y; dst[4 * lane + 2] = sA.z; dst[4 * lane + 3] = sA.w;
+                }
+                if (lane == 63) { dst[16] = sB.x; dst[17] = sB.y; }
+            }
         }
-        s_sum[gl * K8_SUM_STRIDE + q] = acc;
+        // invisible members fold to zero
+        if (my_cnt == 0) {
+#pragma unroll
+            for (int i = 0; i < GRAD_FLOATS; i++) s_sum[t * K8_SUM_STRIDE + i] = 0.0f;
+        }
     }
     __syncthreads();
     if (!in_range) return;
@@ -554,7 +614,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             dmean3[1] = dL_dM[2][1];
             dmean3[2] = dL_dM[2][2];
         }
-        if (a.shs != nullptr) {
+        if (a.shs != nullptr && !(a.dbg_skip & 2)) {
             float sh[48];
             load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
             const F3 dm = sh_backward(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
@@ -567,16 +627,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         // (or, on the precomputed-T path with a centre gradient, the folded one the reference wrote back)
         dmean2[0] = (float)(dT_out[2] * depth_T8 * 0.5 * (float)a.W);
         dmean2[1] = (float)(dT_out[5] * depth_T8 * 0.5 * (float)a.H);
-    } else if (dsh != nullptr) {
-        if (a.sh_vec16) {
-            float4* o4 = reinterpret_cast<float4*>(dsh);
-#pragma unroll
-            for (int q = 0; q < 12; q++) o4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.0f;
-        }
     }
+    // rows of dL_dsh that belong to invisible Gaussians were zero-filled by the caller (one
+    // hipMemsetAsync at copy-engine speed instead of 192-byte strided stores from here)
 
+    if (a.dbg_skip & 4) return;
     a.dL_dmean2D[3 * idx] = dmean2[0]; a.dL_dmean2D[3 * idx + 1] = dmean2[1]; a.dL_dmean2D[3 * idx + 2] = dmean2[2];
     if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5]; }
     a.dL_dopacity[idx] = g[17];
