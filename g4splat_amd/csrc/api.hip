@@ -219,6 +219,7 @@ extern "C" int g4s_rasterizer_forward(
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
         pa.depth_keys = keys_a; pa.gidx = vals_a;
         pa.ref_block_sums = (uint32_t*)(geom + GL.ref_block_sums);
+        pa.idx_block_sums = (uint32_t*)(geom + GL.idx_block_sums);
         { ProfScope ps(PF_PREPROCESS_FWD, stream); launch_preprocess_fwd(pa, stream); }
         CHECK_LAUNCH("preprocess_fwd");
 
@@ -234,6 +235,10 @@ extern "C" int g4s_rasterizer_forward(
           launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs,
                             (const uint32_t*)(geom + GL.ref_block_sums), d_total, GL.nblocks, stream); }
         CHECK_LAUNCH("count scan");
+
+        launch_grad_slots(P, tiles_touched, (const uint32_t*)(geom + GL.idx_block_sums),
+                          (uint32_t*)(geom + GL.idx_block_offs), d_total + 2, rec, GL.nblocks, stream);
+        CHECK_LAUNCH("grad slots");
 
         // the one host synchronisation of the forward (rasterizer_impl.cu:281-282)
         uint32_t* h_total = pinned_word();
@@ -291,8 +296,7 @@ extern "C" int g4s_rasterizer_forward(
 }
 
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
-    (void)P;
-    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + 256;
+    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + align_up((size_t)(P > 0 ? P : 1) * GRAD_FLOATS * 4) + 256;
 }
 
 extern "C" int g4s_rasterizer_backward(
@@ -360,6 +364,7 @@ extern "C" int g4s_rasterizer_backward(
     pb.transMat_precomp = transMat_precomp; pb.colors_precomp = colors_precomp;
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
+    pb.gsum = (float*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));
     pb.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
     pb.dbg_skip = getenv("G4S_K8_SKIP") ? atoi(getenv("G4S_K8_SKIP")) : 0;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;

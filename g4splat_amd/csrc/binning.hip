@@ -259,7 +259,6 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
     s_idx[t] = idx;
     s_rect[t] = (uint32_t)x0 | ((uint32_t)y0 << 16);
     s_rect2[t] = (uint32_t)(x1 - x0);
-    if (cnt > 0) rec[(size_t)idx * REC_FLOATS + 2] = __uint_as_float(base + local);  // inst_off
     __syncthreads();
     for (uint32_t o = (uint32_t)t; o < block_total; o += 256) {
         // largest j with s_off[j] <= o  (zero-count ranks share an offset with their successor,
@@ -278,6 +277,23 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
         entries[(size_t)base + o] =
             (tile << ENTRY_TILE_SHIFT) | ((uint64_t)k << ENTRY_K_SHIFT) | (uint64_t)s_idx[lo];
     }
+}
+
+__global__ void __launch_bounds__(256) grad_slots_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                         const uint32_t* __restrict__ idx_block_offs,
+                                                         float* __restrict__ rec) {
+    __shared__ uint32_t sm4[4];
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    const uint32_t c = idx < P ? tiles_touched[idx] : 0u;
+    uint32_t total;
+    const uint32_t local = block256_excl_scan_u32(c, sm4, &total);
+    if (c > 0) rec[(size_t)idx * REC_FLOATS + 2] = __uint_as_float(idx_block_offs[blockIdx.x] + local);
+}
+void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_sums, uint32_t* idx_block_offs,
+                       uint32_t* scratch_total, float* rec, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
+                       idx_block_sums, scratch_total);
+    hipLaunchKernelGGL(grad_slots_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_touched, idx_block_offs, rec);
 }
 
 void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,

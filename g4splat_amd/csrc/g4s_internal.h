@@ -36,7 +36,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // (the reference's GeometryState/BinningState/ImageState, rasterizer_impl.h:21-73).
 struct GeomLayout {
     size_t rec, clamped, tiles_touched, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
-        block_sums, block_offs, ref_block_sums, total, bytes;
+        block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, total, bytes;
     int nchunks;   // radix chunks over P
     int nblocks;   // 256-wide blocks over P
 };
@@ -67,6 +67,8 @@ inline GeomLayout geom_layout(size_t P) {
     L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.ref_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.idx_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.idx_block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.total = take(256);
     L.bytes = o + 256;  // slack for aligning the chunk base
     return L;
@@ -101,6 +103,7 @@ inline char* align_ptr(char* p) { return (char*)align_up((size_t)p); }
 struct PreprocessArgs {
     int P, D, M, W, H, tiles_x, tiles_y;
     uint32_t* ref_block_sums;  // per 256-Gaussian block: sum of the reference's tiles_touched (3-sigma rect)
+    uint32_t* idx_block_sums;  // per 256-Gaussian block (index order): sum of the binned tile counts
     const float *means3D, *scales, *rotations, *opacities, *shs, *transMat_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;
@@ -128,6 +131,10 @@ int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
                        uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
                        hipStream_t s);
+// Gradient-record slots in INDEX order: rec[idx].inst_off = exclusive scan of tiles_touched over idx
+// (so that the per-Gaussian fold of the backward streams the record buffer sequentially).
+void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_sums, uint32_t* idx_block_offs,
+                       uint32_t* scratch_total, float* rec, int nblocks, hipStream_t s);
 void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,
                  const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
                  hipStream_t s);
@@ -172,6 +179,7 @@ struct PreprocessBwdArgs {
     const float* rec;
     const uint8_t* clamped;
     const float* grad_inst;
+    float* gsum;  // P x 18 folded gradient terms (workspace)
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
     int dbg_skip;   // bring-up/experiments only (G4S_K8_SKIP): 1 = skip fold, 2 = skip SH, 4 = skip small outputs
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,

@@ -256,11 +256,19 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     }
     // num_rendered of the reference = sum of its tiles_touched: per-block partial, summed by the
     // count-scan kernel (a same-address atomic per wave serialises at ~90 atomics/us on this part)
-    __shared__ uint32_t s_ref[4];
+    __shared__ uint32_t s_ref[4], s_tight[4];
     const uint32_t wsum = wave_sum_u32(touched_ref);
-    if (lane_id() == 0) s_ref[threadIdx.x >> 6] = wsum;
+    const uint32_t tsum = wave_sum_u32(touched);
+    if (lane_id() == 0) {
+        s_ref[threadIdx.x >> 6] = wsum;
+        s_tight[threadIdx.x >> 6] = tsum;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.ref_block_sums[blockIdx.x] = (s_ref[0] + s_ref[1]) + (s_ref[2] + s_ref[3]);
+    if (threadIdx.x == 0) {
+        a.ref_block_sums[blockIdx.x] = (s_ref[0] + s_ref[1]) + (s_ref[2] + s_ref[3]);
+        // binned-instance count of this block in INDEX order: base of the gradient-record slots
+        a.idx_block_sums[blockIdx.x] = (s_tight[0] + s_tight[1]) + (s_tight[2] + s_tight[3]);
+    }
 }
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
@@ -411,7 +419,9 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
 // Gaussian.  Every output element is written (zeros for invisible Gaussians).
 constexpr int K8_SUM_STRIDE = GRAD_FLOATS + 1;  // LDS row stride, odd => conflict-free column reads
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+// K8a: fold only (few registers => full occupancy for a latency-bound gather); the per-Gaussian
+// sums go to gsum[P][18] with coalesced stores.
+__global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) {
     __shared__ float s_sum[256 * K8_SUM_STRIDE];
     __shared__ uint32_t s_off[256], s_cnt[256];
     const int t = (int)threadIdx.x;
@@ -442,46 +452,71 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         const uint32_t my_cnt = s_cnt[t], my_off = s_off[t];
         uint64_t vis = __ballot(my_cnt != 0);
         const int kk = lane >> 2, c = lane & 3;
+        constexpr int U = 8;  // Gaussians in flight per iteration
         while (vis) {
-            int jj[4];
-            uint32_t cn[4], of[4];
+            int jj[U];
+            uint32_t cn[U], of[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
                 jj[u] = vis ? (int)__builtin_ctzll(vis) : -1;
                 if (vis) vis &= vis - 1;
                 cn[u] = jj[u] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, jj[u] < 0 ? 0 : jj[u]) : 0u;
                 of[u] = jj[u] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)my_off, jj[u] < 0 ? 0 : jj[u]) : 0u;
             }
-            float4 accA[4];
-            float2 accB[4];
+            // common case first, with every load of the iteration issued before any is consumed:
+            // records 0..15 (terms 0..15, 16 records x 4 quads) and records 0..63 (terms 16..17)
+            float4 accA[U];
+            float2 accB[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
                 const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
                 const float2* base2 = reinterpret_cast<const float2*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
-                float4 sA = make_float4(0.f, 0.f, 0.f, 0.f);
-                float2 sB = make_float2(0.f, 0.f);
-                for (uint32_t k0 = 0; k0 < cn[u]; k0 += 64) {
-                    // terms 0..15: four sub-steps of 16 records x 4 quads
-#pragma unroll
-                    for (int sstep = 0; sstep < 4; sstep++) {
-                        const uint32_t k = k0 + 16 * sstep + kk;
-                        if (k0 + 16 * sstep < cn[u]) {  // uniform
-                            const float4 x = base4[(size_t)(k < cn[u] ? k : 0) * (GRAD_STRIDE / 4) + c];
-                            const float msk = k < cn[u] ? 1.0f : 0.0f;
-                            sA.x += msk * x.x; sA.y += msk * x.y; sA.z += msk * x.z; sA.w += msk * x.w;
-                        }
-                    }
-                    // terms 16..17: one record per lane
-                    const uint32_t kb = k0 + lane;
-                    const float2 y = base2[(size_t)(kb < cn[u] ? kb : 0) * (GRAD_STRIDE / 2) + 8];
-                    const float mb = kb < cn[u] ? 1.0f : 0.0f;
-                    sB.x += mb * y.x; sB.y += mb * y.y;
-                }
-                accA[u] = sA;
-                accB[u] = sB;
+                accA[u] = base4[(size_t)((uint32_t)kk < cn[u] ? kk : 0) * (GRAD_STRIDE / 4) + c];
+                accB[u] = base2[(size_t)((uint32_t)lane < cn[u] ? lane : 0) * (GRAD_STRIDE / 2) + 8];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
+                const float ma = (uint32_t)kk < cn[u] ? 1.0f : 0.0f, mb = (uint32_t)lane < cn[u] ? 1.0f : 0.0f;
+                accA[u].x *= ma; accA[u].y *= ma; accA[u].z *= ma; accA[u].w *= ma;
+                accB[u].x *= mb; accB[u].y *= mb;
+            }
+            // long runs (rare): the remaining records, in ascending order
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (cn[u] <= 16) continue;  // uniform
+                const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
+                const float2* base2 = reinterpret_cast<const float2*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
+                // 128 records per trip: eight independent 16-byte loads + two 8-byte loads in flight per
+                // lane, so a Gaussian with thousands of instances is not a serial chain of round trips
+                for (uint32_t k0 = 16; k0 < cn[u]; k0 += 128) {
+                    float4 x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t k = k0 + 16 * i + kk;
+                        x[i] = base4[(size_t)(k < cn[u] ? k : 0) * (GRAD_STRIDE / 4) + c];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const float msk = (k0 + 16 * i + kk) < cn[u] ? 1.0f : 0.0f;
+                        accA[u].x += msk * x[i].x; accA[u].y += msk * x[i].y; accA[u].z += msk * x[i].z; accA[u].w += msk * x[i].w;
+                    }
+                }
+                for (uint32_t k0 = 64; k0 < cn[u]; k0 += 256) {
+                    float2 y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t kb = k0 + 64 * i + lane;
+                        y[i] = base2[(size_t)(kb < cn[u] ? kb : 0) * (GRAD_STRIDE / 2) + 8];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float mb = (k0 + 64 * i + lane) < cn[u] ? 1.0f : 0.0f;
+                        accB[u].x += mb * y[i].x; accB[u].y += mb * y[i].y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
                 if (jj[u] < 0) continue;  // uniform
                 float4 sA = accA[u];
                 float2 sB = accB[u];
@@ -504,6 +539,29 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 #pragma unroll
             for (int i = 0; i < GRAD_FLOATS; i++) s_sum[t * K8_SUM_STRIDE + i] = 0.0f;
         }
+    }
+    __syncthreads();
+    // coalesced write-out of the block's 256 x 18 sums
+    {
+        const size_t gbase = (size_t)blockIdx.x * 256 * GRAD_FLOATS;
+        const int nvalid = imin_(256, a.P - (int)blockIdx.x * 256) * GRAD_FLOATS;
+        for (int i = t; i < nvalid; i += 256) a.gsum[gbase + i] = s_sum[(i / GRAD_FLOATS) * K8_SUM_STRIDE + (i % GRAD_FLOATS)];
+    }
+}
+
+// K8b: one thread per Gaussian; the folded terms arrive through LDS (coalesced load of the block's
+// 256 x 18 floats).
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+    __shared__ float s_sum[256 * K8_SUM_STRIDE];
+    const int t = (int)threadIdx.x;
+    const int idx = (int)(blockIdx.x * 256 + t);
+    const bool in_range = idx < a.P;
+    const bool visible = in_range && a.radii[idx] > 0;
+    const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)(in_range ? idx : 0) * REC_QUADS;
+    {
+        const size_t gbase = (size_t)blockIdx.x * 256 * GRAD_FLOATS;
+        const int nvalid = imin_(256, a.P - (int)blockIdx.x * 256) * GRAD_FLOATS;
+        for (int i = t; i < nvalid; i += 256) s_sum[(i / GRAD_FLOATS) * K8_SUM_STRIDE + (i % GRAD_FLOATS)] = a.gsum[gbase + i];
     }
     __syncthreads();
     if (!in_range) return;
@@ -645,6 +703,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
+    hipLaunchKernelGGL(fold_records_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 

@@ -85,7 +85,7 @@ int g4s_rasterizer_forward(
     float* out_color, float* out_others, int* radii, int debug, void* stream);
 
 /* Bytes of transient workspace g4s_rasterizer_backward needs for a forward that
- * returned R (per-instance gradient records, 80 B each + alignment). */
+ * returned R (per-instance gradient records, 80 B each, + 72 B per Gaussian + alignment). */
 size_t g4s_rasterizer_backward_workspace(int P, int R);
 
 /*

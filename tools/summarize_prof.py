@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         cnt[k][r["Counter_Name"]] += 1
 print("== PMC (mean per dispatch)")
 for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
-    if not any(s in k for s in ("blend", "preprocess", "radix", "emit", "tile_ranges", "count", "scan")):
+    if not any(s in k for s in ("blend", "preprocess", "radix", "emit", "tile_", "count", "scan", "fold", "grad_slots", "knn")):
         continue
     print(k)
     for c in sorted(agg[k]):
