@@ -1,0 +1,82 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/g4s_rasterizer.h declares;
+the ctypes signature table of the Python front-end matches the header (no compute calls here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "g4s_rasterizer.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    src = re.sub(r"typedef[^;]*;", "", src)
+    decls = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(g4s_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        args = [a.strip() for a in m.group(3).replace("\n", " ").split(",")]
+        if args == ["void"] or args == [""]:
+            args = []
+        decls[m.group(2)] = (m.group(1).strip(), args)
+    return decls
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from g4splat_amd import _lib
+    decls = declared_functions()
+    assert len(decls) >= 12
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True)
+    exported = {line.split()[-1] for line in out.stdout.splitlines() if " T " in line}
+    for name in decls:
+        assert name in exported, f"{name} declared in the header but not exported"
+        assert hasattr(hip_lib, name)
+    for name in exported:
+        if name.startswith("g4s_") and not name.endswith("_internal"):
+            assert name in decls, f"{name} exported but not declared in include/g4s_rasterizer.h"
+
+
+def test_ctypes_table_matches_header(hip_lib):
+    from g4splat_amd import _lib
+    decls = declared_functions()
+    assert set(_lib.SIGNATURES) == set(decls)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        assert len(args) == len(decls[name][1]), f"{name}: {len(args)} ctypes args vs {len(decls[name][1])} in header"
+
+
+def test_version_and_error_strings(hip_lib):
+    assert hip_lib.g4s_version().startswith(b"g4s-hip") and b"gfx950" in hip_lib.g4s_version()
+    assert hip_lib.g4s_last_error() == b""
+    assert hip_lib.g4s_knn_workspace(1000) > 0
+    assert hip_lib.g4s_rasterizer_backward_workspace(10, 100) >= 100 * 80
+    # layout query is pure host code
+    import ctypes
+    L = _layout(hip_lib, 1000, 5000, 640, 480)
+    assert L.rec == 0 and L.geom_bytes > 1000 * 96 and L.binning_bytes > 2 * 5000 * 8 and L.image_bytes > 640 * 480 * 20
+    assert hip_lib.g4s_rasterizer_layout(-1, 0, 0, 0, ctypes.byref(L)) < 0
+    assert b"bad layout" in hip_lib.g4s_last_error()
+
+
+def _layout(lib, P, R, W, H):
+    import ctypes
+    from g4splat_amd import _lib
+    L = _lib.G4sLayout()
+    assert lib.g4s_rasterizer_layout(P, R, W, H, ctypes.byref(L)) == 0
+    return L
+
+
+def test_oracle_library_builds_and_is_not_linked_into_product(hip_lib, oracle_mod):
+    from g4splat_amd import _lib
+    out = subprocess.run(["ldd", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert "surfel_oracle" not in out
+    # nothing under g4splat_amd/ may import the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "g4splat_amd")):
+        for f in files:
+            txt = open(os.path.join(dirpath, f), errors="ignore").read() if f.endswith((".py", ".hip", ".h")) else ""
+            if f.endswith(".py"):
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "libsurfel_oracle" not in txt, f
+            elif txt:
+                assert not re.search(r"#\s*include\s+[\"<][^\">]*oracle", txt), f
