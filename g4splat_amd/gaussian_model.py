@@ -1,0 +1,109 @@
+"""Minimal GaussianModel-compatible parameter container: exactly the attributes `render()` and the
+training loop read (2dgs/scene/gaussian_model.py:157-266) -- getters with the reference's activations,
+`create_from_pcd` (distCUDA2 scale init), `create_from_parameters`, Adam groups with the reference's
+names / eps, and the densification statistics.  Densify / prune / PLY I/O are SURVEY.md 8(f) f3-f4."""
+import torch
+from torch import nn
+
+C0 = 0.28209479177387814
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianModel:
+    def __init__(self, sh_degree=3, use_mip_filter=False):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.use_mip_filter = use_mip_filter
+        self.mip_filter = None
+        e = torch.empty(0)
+        self._xyz = self._features_dc = self._features_rest = self._scaling = self._rotation = self._opacity = e
+        self.max_radii2D = self.xyz_gradient_accum = self.denom = e
+        self.optimizer = None
+        self.spatial_lr_scale = 1.0
+
+    # ---- activations / getters (gaussian_model.py:157-192) ----------------------------------
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        s = torch.exp(self._scaling)
+        if self.use_mip_filter:
+            s = torch.sqrt(torch.square(s) + torch.square(self.mip_filter))
+        return s
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        o = torch.sigmoid(self._opacity)
+        if self.use_mip_filter:
+            s2 = torch.square(torch.exp(self._scaling))
+            o = o * torch.sqrt(s2.prod(dim=1) / (s2 + torch.square(self.mip_filter)).prod(dim=1))[..., None]
+        return o
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    def parameters(self):
+        return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]
+
+    # ---- construction ------------------------------------------------------------------------------
+    def _set(self, xyz, colors, log_scales, rots, opacity=0.1):
+        n, dev = xyz.shape[0], xyz.device
+        feats = torch.zeros((n, 3, (self.max_sh_degree + 1) ** 2), device=dev)
+        feats[:, :3, 0] = (colors - 0.5) / C0
+        self._xyz = nn.Parameter(xyz.clone().float().requires_grad_(True))
+        self._features_dc = nn.Parameter(feats[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(feats[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
+        self._scaling = nn.Parameter(log_scales.float().requires_grad_(True))
+        self._rotation = nn.Parameter(rots.float().requires_grad_(True))
+        self._opacity = nn.Parameter(inverse_sigmoid(opacity * torch.ones((n, 1), device=dev)).requires_grad_(True))
+        self.max_radii2D = torch.zeros(n, device=dev)
+
+    def create_from_pcd(self, points, colors, spatial_lr_scale=1.0):
+        """gaussian_model.py:201-223: isotropic scale = sqrt(mean squared distance to the 3 nearest points)."""
+        from .simple_knn._C import distCUDA2
+        self.spatial_lr_scale = spatial_lr_scale
+        dist2 = torch.clamp_min(distCUDA2(points.float()), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 2)
+        rots = torch.rand((points.shape[0], 4), device=points.device)
+        self._set(points, colors, scales, rots)
+
+    def create_from_parameters(self, means, scales, quaternions, colors, spatial_lr_scale=1.0):
+        """gaussian_model.py:225-246 (the path G4Splat's trainer uses)."""
+        self.spatial_lr_scale = spatial_lr_scale
+        self._set(means, colors, torch.log(scales), quaternions)
+
+    # ---- optimisation ------------------------------------------------------------------------------
+    def training_setup(self, position_lr=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
+                       rotation_lr=0.001):
+        n, dev = self._xyz.shape[0], self._xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        groups = [
+            {"params": [self._xyz], "lr": position_lr * self.spatial_lr_scale, "name": "xyz"},
+            {"params": [self._features_dc], "lr": feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": rotation_lr, "name": "rotation"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """gaussian_model.py:649-651: accumulate the per-view norm of the screen-space gradient."""
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1,
+                                                             keepdim=True)
+        self.denom[update_filter] += 1

@@ -1,0 +1,134 @@
+"""One-view-per-rank data parallelism over `gloo`, world_size 2, on CPU:
+the all-reduced gradient bucket equals the sum of the single-process gradients over the same views
+(no optimiser step in between), the side channel follows the per-view-norm semantics, and both
+replicas stay identical after the Adam step."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _setup_paths():
+    root = os.path.dirname(HERE)
+    for p in (root, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _views(n, W=48, H=40):
+    from g4splat_amd import synthetic
+    out = []
+    for i in range(n):
+        a = 0.5 * i
+        cam = synthetic.look_at_camera((2.5 * np.sin(a), 0.2 * i, -2.5 * np.cos(a)), (0, 0, 0), (0, 1, 0), 1.0, W, H)
+        out.append(SimpleNamespace(image_width=W, image_height=H, FoVx=cam.FoVx, FoVy=cam.FoVy,
+                                   world_view_transform=torch.tensor(cam.world_view_transform),
+                                   full_proj_transform=torch.tensor(cam.full_proj_transform),
+                                   camera_center=torch.tensor(cam.camera_center), znear=0.01, zfar=100.0))
+    return out
+
+
+def _model(seed=0, P=150):
+    from g4splat_amd.gaussian_model import GaussianModel
+    rng = np.random.default_rng(seed)
+    m = GaussianModel(sh_degree=3)
+    m.create_from_parameters(torch.tensor(rng.uniform(-0.8, 0.8, (P, 3)).astype(np.float32)),
+                             torch.tensor(rng.uniform(0.05, 0.2, (P, 2)).astype(np.float32)),
+                             torch.tensor(rng.normal(size=(P, 4)).astype(np.float32)),
+                             torch.tensor(rng.uniform(0, 1, (P, 3)).astype(np.float32)))
+    with torch.no_grad():
+        m._opacity += 2.0
+        m._features_rest += torch.tensor(rng.normal(0, 0.05, tuple(m._features_rest.shape)).astype(np.float32))
+    m.active_sh_degree = 2
+    return m
+
+
+def _step(model, views, vp):
+    from cpu_rasterizer import OracleRasterizer
+    from g4splat_amd.gaussian_renderer import render
+    pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False)
+    for v in views:
+        out = render(v, model, pipe, torch.tensor([0.0, 0.1, 0.2]), rasterizer_cls=OracleRasterizer)
+        loss = (out["render"] ** 2).mean() + 0.1 * out["rend_dist"].mean() + 0.05 * out["rend_alpha"].mean()
+        loss.backward()
+        vp.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
+
+
+def _worker(rank, world, port, q):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from g4splat_amd.parallel import ViewParallel, broadcast_parameters, shard_views
+    torch.set_num_threads(1)
+    model = _model(seed=rank)  # deliberately different replicas: the broadcast must fix that
+    broadcast_parameters(model.parameters(), src=0)
+    model.training_setup()
+    vp = ViewParallel(model.parameters())
+    views = _views(4)
+    mine = shard_views(views, rank, world)
+    assert len(mine) == 2
+    _step(model, mine, vp)
+    stats = vp.all_reduce()
+    flat = vp.bucket.flat.clone()
+    model.optimizer.step()
+    q.put((rank, flat.numpy(), stats["grad_norm_sum"].numpy(), stats["vis_count"].numpy(), stats["max_radii"].numpy(),
+           torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_parallel_matches_single_process():
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=240)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    # single-process reference: all four views on one replica, gradients accumulated, no step in between
+    from g4splat_amd.parallel import ViewParallel
+    model = _model(seed=0)
+    model.training_setup()
+    vp = ViewParallel(model.parameters())
+    _step(model, _views(4), vp)
+    ref = vp.bucket.flat.numpy()
+    for r in (0, 1):
+        flat, gsum, cnt, rad, params = res[r]
+        assert np.abs(flat - ref).max() <= 1e-3 * np.abs(ref).max()
+        np.testing.assert_allclose(gsum, vp.grad_norm_sum.numpy(), rtol=1e-4, atol=1e-7)
+        np.testing.assert_array_equal(cnt, vp.vis_count.numpy())
+        np.testing.assert_array_equal(rad, vp.max_radii.numpy())
+    # replicas identical after the step (deterministic Adam on identical reduced gradients)
+    np.testing.assert_array_equal(res[0][4], res[1][4])
+    # 58 floats per Gaussian in the bucket
+    assert ref.size == 150 * 58
+
+
+def test_bucket_views_survive_zero_grad():
+    _setup_paths()
+    from g4splat_amd.parallel import GradientBucket
+    ps = [torch.nn.Parameter(torch.ones(4, 3)), torch.nn.Parameter(torch.ones(4, 1))]
+    b = GradientBucket(ps)
+    (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+    assert b.flat.tolist() == [2.0] * 12 + [3.0] * 4
+    opt = torch.optim.Adam(ps)
+    opt.zero_grad(set_to_none=True)
+    b.zero()
+    (ps[0].sum()).backward()
+    assert b.flat.tolist() == [1.0] * 12 + [0.0] * 4

@@ -1,0 +1,99 @@
+"""render(): dict keys / shapes / post-processing semantics (2dgs/gaussian_renderer/__init__.py:108-166),
+driven on the CPU through the oracle-backed rasterizer stand-in."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from cpu_rasterizer import OracleRasterizer
+from g4splat_amd import synthetic
+from g4splat_amd.gaussian_model import GaussianModel
+from g4splat_amd.gaussian_renderer import depth_to_normal, render
+
+KEYS = {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_normal_cam",
+        "rend_dist", "surf_depth", "surf_normal", "surf_normal_cam", "rend_depth"}
+
+
+def _camera(W=80, H=56):
+    cam = synthetic.look_at_camera((0.3, -0.2, -3.0), (0, 0, 0), (0, 1, 0), 1.0, W, H)
+    return SimpleNamespace(image_width=W, image_height=H, FoVx=cam.FoVx, FoVy=cam.FoVy,
+                           world_view_transform=torch.tensor(cam.world_view_transform),
+                           full_proj_transform=torch.tensor(cam.full_proj_transform),
+                           camera_center=torch.tensor(cam.camera_center), znear=0.01, zfar=100.0)
+
+
+def _model(P=300, seed=0):
+    rng = np.random.default_rng(seed)
+    m = GaussianModel(sh_degree=3)
+    pts = torch.tensor(rng.uniform(-1, 1, (P, 3)).astype(np.float32))
+    m.create_from_parameters(pts, torch.tensor(rng.uniform(0.05, 0.2, (P, 2)).astype(np.float32)),
+                             torch.tensor(rng.normal(size=(P, 4)).astype(np.float32)),
+                             torch.tensor(rng.uniform(0, 1, (P, 3)).astype(np.float32)))
+    with torch.no_grad():
+        m._opacity += 2.0
+    m.active_sh_degree = 1
+    return m
+
+
+def test_render_dict_and_gradients():
+    cam, model = _camera(), _model()
+    pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False, convert_SHs_python=False)
+    out = render(cam, model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer)
+    assert set(out) == KEYS
+    H, W = 56, 80
+    assert out["render"].shape == (3, H, W) and out["rend_alpha"].shape == (1, H, W)
+    assert out["rend_normal"].shape == (3, H, W) and out["surf_normal"].shape == (3, H, W)
+    assert out["surf_depth"].shape == (1, H, W) and out["rend_dist"].shape == (1, H, W)
+    assert out["radii"].dtype == torch.int32 and out["visibility_filter"].dtype == torch.bool
+    a = out["rend_alpha"]
+    assert float(a.max()) > 0.5 and float(a.min()) >= 0
+    # expected depth = D / alpha with nan_to_num; median depth only where T crossed 0.5
+    assert torch.isfinite(out["surf_depth"]).all() and torch.isfinite(out["rend_depth"]).all()
+    # world normal = cam normal rotated by W2C^T rows: norms agree
+    assert torch.allclose(out["rend_normal"].norm(dim=0), out["rend_normal_cam"].norm(dim=0), atol=1e-5)
+    loss = out["render"].mean() + out["rend_dist"].mean() + (1 - (out["rend_normal"] * out["surf_normal"]).sum(0)).mean()
+    loss.backward()
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert out["viewspace_points"].grad is not None and out["viewspace_points"].grad.shape == model.get_xyz.shape
+    model.training_setup()
+    model.add_densification_stats(out["viewspace_points"], out["visibility_filter"])
+    assert float(model.denom.sum()) == float(out["visibility_filter"].sum())
+
+
+def test_python_cov3d_path_matches_kernel_path():
+    """pipe.compute_cov3D_python: T built in python (render(), :64-75) must reproduce the in-kernel T."""
+    cam, model = _camera(), _model(P=120, seed=3)
+    model.get_covariance = lambda mod=1: _covariance(model, mod)
+    bg = torch.zeros(3)
+    a = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False), bg, rasterizer_cls=OracleRasterizer)
+    b = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=True), bg, rasterizer_cls=OracleRasterizer)
+    assert torch.allclose(a["render"], b["render"], atol=2e-4)
+    assert torch.allclose(a["rend_alpha"], b["rend_alpha"], atol=2e-4)
+
+
+def _covariance(model, mod):
+    # build_covariance_from_scaling_rotation, gaussian_model.py:30-36 (note: uses the RAW _rotation, normalised inside)
+    q = torch.nn.functional.normalize(model._rotation)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    s = torch.cat([model.get_scaling * mod, torch.ones_like(model.get_scaling[:, :1])], 1)
+    RS = (R * s[:, None, :]).permute(0, 2, 1)
+    trans = torch.zeros((q.shape[0], 4, 4))
+    trans[:, :3, :3] = RS
+    trans[:, 3, :3] = model.get_xyz
+    trans[:, 3, 3] = 1
+    return trans
+
+
+def test_depth_to_normal_of_a_plane():
+    cam = _camera(64, 48)
+    depth = torch.full((1, 48, 64), 2.0)
+    n = depth_to_normal(cam, depth)
+    inner = n[1:-1, 1:-1]
+    # a fronto-parallel plane: normal = -+ camera forward axis in world space
+    fwd = torch.linalg.inv(cam.world_view_transform.T)[:3, 2]
+    assert torch.allclose(inner.reshape(-1, 3).abs() @ torch.ones(3), (fwd.abs() @ torch.ones(3)).expand(inner.numel() // 3), atol=1e-3)
+    assert not n[0].any() and not n[:, 0].any()
