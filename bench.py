@@ -153,9 +153,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_step = []
     for i in range(args.steps):
+        ts = time.perf_counter()
         step(i)
+        if os.environ.get("G4S_BENCH_PER_STEP"):
+            torch.cuda.synchronize()
+            per_step.append(round((time.perf_counter() - ts) * 1e3, 2))
     torch.cuda.synchronize()
+    if per_step and rank == 0:
+        print("per-step ms:", per_step, file=sys.stderr)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -67,13 +67,20 @@ const char* const kProfNames[PF_COUNT] = {"preprocess_fwd", "depth_sort", "count
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
-std::vector<ProfRec> g_prof;
+std::vector<ProfRec> g_prof;          // recorded (kernel group, start, stop)
+std::vector<hipEvent_t> g_prof_pool;  // events are created up front, never inside a timed region
+size_t g_prof_next = 0;
+constexpr size_t PROF_POOL = 16384;
 
 struct ProfScope {
-    int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_prof_on) {
-        if (on && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
-        else on = false;
+    int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on = false;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) {
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_next + 2 > g_prof_pool.size()) return;  // pool exhausted: stop recording
+        a = g_prof_pool[g_prof_next++];
+        b = g_prof_pool[g_prof_next++];
+        on = hipEventRecord(a, s) == hipSuccess;
     }
     ~ProfScope() {
         if (!on) return;
@@ -99,6 +106,14 @@ extern "C" const char* g4s_last_error(void) { return t_err; }
 
 extern "C" void g4s_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on && g_prof_pool.empty()) {
+        g_prof_pool.reserve(PROF_POOL);
+        for (size_t i = 0; i < PROF_POOL; i++) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            g_prof_pool.push_back(e);
+        }
+    }
     g_prof_on = on != 0;
 }
 extern "C" int g4s_profile_kernels(void) { return PF_COUNT; }
@@ -121,8 +136,8 @@ extern "C" int g4s_profile_read(int id, double* total_ms, int* count) {
 }
 extern "C" void g4s_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (const ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
+    g_prof_next = 0;  // the pooled events are reused
 }
 extern "C" const char* g4s_version(void) { return "g4s-hip 0.1.0 gfx950"; }
 
@@ -183,6 +198,7 @@ extern "C" int g4s_rasterizer_forward(
     int R = 0;
     const float* rec_ptr = nullptr;
     const uint64_t* entries_ptr = nullptr;
+    uint8_t* qhit_ptr = nullptr;
     if (P > 0) {
         if (!means3D || !opacities) return fail(G4S_ERR_INVALID_ARGUMENT, "means3D / opacities must not be NULL");
         if (!shs && !colors_precomp)  // NUM_CHANNELS == 3 here; mirrors rasterizer_impl.cu:243-246
@@ -259,7 +275,9 @@ extern "C" int g4s_rasterizer_forward(
         uint64_t* ent_a = (uint64_t*)(bin + BL.ent_a);
         uint64_t* ent_b = (uint64_t*)(bin + BL.ent_b);
         entries_ptr = ent_a;
+        qhit_ptr = (uint8_t*)(bin + BL.qhit);
         if (R_binned > 0) {
+            HIP_TRY(hipMemsetAsync(qhit_ptr, 0, align_up((size_t)R_binned, 256), stream));  // whole 256-B granules: a ragged byte count takes a slow fill path
             { ProfScope ps(PF_EMIT, stream);
               launch_emit(P, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, GL.nblocks,
                           stream); }
@@ -289,6 +307,7 @@ extern "C" int g4s_rasterizer_forward(
     ba.W = width; ba.H = height; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y;
     ba.ranges = ranges; ba.tile_order = tile_order; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
+    ba.qhit = qhit_ptr;
     if (getenv("G4S_SKIP_BLEND")) return R;  // bring-up aid: leave the binning state for inspection
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");
@@ -336,6 +355,8 @@ extern "C" int g4s_rasterizer_backward(
     // dL_dsh is mostly zero rows (invisible Gaussians): fill it once at memset speed, K8 only writes
     // the visible rows.  Issued ahead of the (VALU-bound) blend backward.
     if (M > 0) HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * M * 3 * sizeof(float), stream));
+    // gradient records: only instances that receive a contribution are written by the blend backward
+    if (R > 0) HIP_TRY(hipMemsetAsync(grad_inst, 0, (size_t)R * GRAD_STRIDE * sizeof(float), stream));
     if (R > 0) {
         char* bin = align_ptr(binning_buffer);
         const int tile_bits = (int)higher_msb((uint32_t)tiles);
@@ -348,7 +369,9 @@ extern "C" int g4s_rasterizer_backward(
         bb.rec = rec; bb.bg = background;
         bb.final_T = (const float*)(img + IL.final_T);
         bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
+        bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst;
+        bb.dbg = getenv("G4S_BWD_DBG") ? atoi(getenv("G4S_BWD_DBG")) : 0;
         { ProfScope ps(PF_BLEND_BWD, stream); launch_blend_bwd(bb, stream); }
         CHECK_LAUNCH("blend_bwd");
     }

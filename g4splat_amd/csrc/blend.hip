@@ -35,6 +35,7 @@ constexpr int FWD_BATCH = 256;
 
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[REC_QUADS][FWD_BATCH];
+    __shared__ unsigned long long s_hit[FWD_BATCH / 64][4];  // [group][quadrant]: entries some pixel blended
     const int tile = (int)a.tile_order[blockIdx.x];
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
     const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
@@ -65,8 +66,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < REC_QUADS; i++) s_rec[i][threadIdx.x] = r[i];
         }
+        if (threadIdx.x < (FWD_BATCH / 64) * 4) (&s_hit[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
-        if (__all(done)) continue;  // this quadrant is finished; keep taking part in the staging
+        if (!__all(done)) {
         // Each group of 64 staged entries is first filtered against this wave's quadrant with one
         // box test per lane + a ballot; only entries whose alpha-cutoff box touches the quadrant are
         // visited (scalar bit scan), so a rejected entry costs ~1/64 of a loop iteration.
@@ -74,23 +76,25 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
             const int jl = g0 + lane;
             const bool rel = jl < m && !quad_misses_box(s_rec[5][jl < FWD_BATCH ? jl : 0], qxf, qyf);
             uint64_t todo = __ballot(rel);
+            uint64_t hit = 0;  // wave-uniform: entries of this group blended by some pixel of this quadrant
             while (todo) {
                 if (__all(done)) break;
-                const int j = g0 + (int)__builtin_ctzll(todo);
+                const int bit = (int)__builtin_ctzll(todo);
+                const int j = g0 + bit;
                 todo &= todo - 1;
-                if (done) continue;
+                bool blended = false;
+                if (!done) {
                 // `contributor` of the reference = 1-based list position (forward.cu:349)
                 const uint32_t contributor = (uint32_t)(b0 + j + 1);
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
                 PairEval e;
-                if (!eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e))
-                    continue;
+                if (eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e)) {
                 const float alpha = e.alpha, depth = e.depth;
                 const float test_T = T * (1 - alpha);
                 if (test_T < 0.0001f) {
                     done = true;
-                    continue;
-                }
+                } else {
+                blended = true;
                 const float w = alpha * T;
                 const float A = 1 - T;
                 const float md = mscale * (1 - NEAR_N * __builtin_amdgcn_rcpf(depth));
@@ -110,8 +114,22 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
                 C2 = fmaf(q4.w, w, C2);
                 T = test_T;
                 last_contributor = contributor;
+                }
+                }
+                }
+                if (__any(blended)) hit |= 1ull << bit;
             }
+            if (lane == 0 && hit) s_hit[g0 >> 6][wv] = hit;
             if (__all(done)) break;
+        }
+        }
+        // contribution mask for the backward: one byte per staged entry, bit q = quadrant q blended it
+        __syncthreads();
+        if ((int)threadIdx.x < m) {
+            const int g = (int)threadIdx.x >> 6, b = (int)threadIdx.x & 63;
+            const uint32_t nib = (uint32_t)((s_hit[g][0] >> b) & 1ull) | ((uint32_t)((s_hit[g][1] >> b) & 1ull) << 1) |
+                                 ((uint32_t)((s_hit[g][2] >> b) & 1ull) << 2) | ((uint32_t)((s_hit[g][3] >> b) & 1ull) << 3);
+            if (nib) a.qhit[r0 + b0 + threadIdx.x] = (uint8_t)nib;
         }
     }
     if (inside) {
@@ -154,7 +172,7 @@ struct BwdPixel {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[REC_QUADS - 1][BWD_BATCH];  // the box quad is consumed at staging time
+    __shared__ float4 s_rec[REC_QUADS - 1][BWD_BATCH];  // the box quad is not needed here
     __shared__ uint32_t s_slot[BWD_BATCH];
 
     const int tile = (int)a.tile_order[blockIdx.x];
@@ -203,45 +221,35 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
     const bool row_writer = (lane & 15) == 15;
     const int row = lane >> 4;
 
-    // per-quadrant live bounds (wave-uniform): list positions >= the quadrant's max last_contributor
-    // cannot contribute in that quadrant; >= the tile's maximum nowhere
-    uint32_t qlive[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) qlive[q] = wave_max_u32(p[q].last_c);
-    const int n_live = (int)max(max(qlive[0], qlive[1]), max(qlive[2], qlive[3]));
-    (void)max_last;
-    for (int j = n_live + lane; j < n; j += 64) {
-        const uint64_t e = a.entries[r0 + j];
-        const uint32_t slot = __float_as_uint(a.rec[(size_t)entry_idx(e) * REC_FLOATS + 2]) + entry_k(e);
-        float4* dst = reinterpret_cast<float4*>(a.grad_inst + (size_t)slot * GRAD_STRIDE);
-#pragma unroll
-        for (int i = 0; i < GRAD_STRIDE / 4; i++) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    // list positions >= the tile's max last_contributor cannot contribute anywhere
+    const int n_live = (int)wave_max_u32(max_last);
+    // (records of instances that receive no contribution are never written: the caller clears the
+    //  record buffer with one streaming memset instead of ~Rb scattered 80-byte zero stores)
 
     // batches from the back of the live range; lane t stages list position hi-1-t
     for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
         const int m = imin_(BWD_BATCH, hi);
         __syncthreads();
-        uint32_t qmask = 0;  // bit q: quadrant q can be touched by the entry this lane staged
+        // bit q of qmask: some pixel of quadrant q blended the entry this lane stages -- recorded by
+        // the forward (qhit).  A pixel is active here iff it blended the entry there (same eval, and
+        // every passing entry below last_contributor was blended), so this mask is exact: entries and
+        // quadrants without contribution are never touched.
+        uint32_t qmask = 0;
         if (lane < m) {
+            const uint32_t pos_l = (uint32_t)(hi - 1 - lane);
+            qmask = a.qhit[r0 + pos_l];
+        }
+        if (qmask != 0) {
             const uint32_t pos_l = (uint32_t)(hi - 1 - lane);
             const uint64_t e = a.entries[r0 + pos_l];
             const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
-            const float4 q0 = r[0], box = r[5];
-            s_rec[0][lane] = q0;
+            float4 rq[REC_QUADS - 1];
 #pragma unroll
-            for (int i = 1; i < REC_QUADS - 1; i++) s_rec[i][lane] = r[i];
-            const uint32_t slot = __float_as_uint(q0.z) + entry_k(e);
-            s_slot[lane] = slot;
+            for (int i = 0; i < REC_QUADS - 1; i++) rq[i] = r[i];  // all loads in flight before any LDS store
+            const float4 q0 = rq[0];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (pos_l < qlive[q] && !quad_misses_box(box, (float)(tx0 + (q & 1) * 8), (float)(ty0 + (q >> 1) * 8)))
-                    qmask |= 1u << q;
-            if (qmask == 0) {  // dead for every quadrant: its record is zero, written right here
-                float4* dst = reinterpret_cast<float4*>(a.grad_inst + (size_t)slot * GRAD_STRIDE);
-#pragma unroll
-                for (int i = 0; i < GRAD_STRIDE / 4; i++) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < REC_QUADS - 1; i++) s_rec[i][lane] = rq[i];
+            s_slot[lane] = __float_as_uint(q0.z) + entry_k(e);
         }
         __syncthreads();
 
@@ -262,9 +270,10 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
                 BwdPixel& x = p[q];
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
-                bool act = pos < x.last_c;
+                bool act = pos < x.last_c && !(a.dbg & 4);
                 if (act)
                     act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                if (a.dbg & 2) { g[0] += act ? e.G : 0.0f; act = false; }
                 if (!__any(act)) continue;
                 any_active = true;
                 if (act) {
@@ -339,15 +348,12 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
             // 256 pixels -> 1: the four pixels of a lane were summed in registers above, the 64 lanes
             // are summed four terms at a time; row k of sum_i then holds term 4 i + k.
             float* dst = a.grad_inst + (size_t)s_slot[j] * GRAD_STRIDE + row;
-            if (any_active) {
+            if (any_active && !(a.dbg & 1)) {
 #pragma unroll
                 for (int i = 0; i < GRAD_STRIDE / 4; i++) {
                     const float r = wave_sum4_to_rows(g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3]);
                     if (row_writer) dst[4 * i] = r;
                 }
-            } else if (row_writer) {
-#pragma unroll
-                for (int i = 0; i < GRAD_STRIDE / 4; i++) dst[4 * i] = 0.0f;
             }
         }
     }

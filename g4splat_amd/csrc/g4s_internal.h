@@ -41,7 +41,7 @@ struct GeomLayout {
     int nblocks;   // 256-wide blocks over P
 };
 struct BinLayout {
-    size_t ent_a, ent_b, hist, bin_total, bytes;
+    size_t ent_a, ent_b, hist, bin_total, qhit, bytes;
     int nchunks;
 };
 struct ImgLayout {
@@ -82,6 +82,7 @@ inline BinLayout bin_layout(size_t R) {
     L.ent_b = take((R ? R : 1) * 8);
     L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
     L.bin_total = take(256 * 4);
+    L.qhit = take((R ? R : 1));
     L.bytes = o + 256;
     return L;
 }
@@ -151,6 +152,7 @@ struct BlendFwdArgs {
     const float* bg;
     float* final_T;
     uint32_t* n_contrib;
+    uint8_t* qhit;  // per sorted instance: bit q set if some pixel of quadrant q blended it (pre-zeroed)
     float* out_color;
     float* out_others;
 };
@@ -165,9 +167,11 @@ struct BlendBwdArgs {
     const float* bg;
     const float* final_T;
     const uint32_t* n_contrib;
+    const uint8_t* qhit;
     const float* dL_dpix;
     const float* dL_depths;
-    float* grad_inst;  // R x GRAD_FLOATS
+    float* grad_inst;  // R x GRAD_STRIDE
+    int dbg;           // experiments only (G4S_BWD_DBG): 1 skip reduction, 2 skip gradient math, 4 skip evaluation
 };
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 
