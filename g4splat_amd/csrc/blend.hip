@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
             float g[GRAD_STRIDE];
 #pragma unroll
             for (int i = 0; i < GRAD_STRIDE; i++) g[i] = 0.0f;
-            bool any_active = false;
+            bool any_active = false, lowpass = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!((qm >> q) & 1u)) continue;  // scalar branch
@@ -341,6 +341,7 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
                         g[15] = fmaf(c2, e.dx, g[15]);
                         g[16] = fmaf(c2, e.dy, g[16]);
                         g[14] += dL_dz;
+                        lowpass = true;
                     }
                     g[17] = fmaf(G, dL_dalpha, g[17]);
                 }
@@ -348,11 +349,22 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
             // 256 pixels -> 1: the four pixels of a lane were summed in registers above, the 64 lanes
             // are summed four terms at a time; row k of sum_i then holds term 4 i + k.
             float* dst = a.grad_inst + (size_t)s_slot[j] * GRAD_STRIDE + row;
+            // Record layout: floats 0..14 = terms 0..14 (colour, normal, T), 15 = opacity term, 16..17 = the
+            // low-pass centre terms -- those are non-zero only when some pixel took the 2-D filter branch
+            // (rare for splats wider than a pixel), so their group is reduced and stored only then; the
+            // record buffer is pre-cleared.
             if (any_active && !(a.dbg & 1)) {
-#pragma unroll
-                for (int i = 0; i < GRAD_STRIDE / 4; i++) {
-                    const float r = wave_sum4_to_rows(g[4 * i], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3]);
-                    if (row_writer) dst[4 * i] = r;
+                const float r0 = wave_sum4_to_rows(g[0], g[1], g[2], g[3]);
+                if (row_writer) dst[0] = r0;
+                const float r1 = wave_sum4_to_rows(g[4], g[5], g[6], g[7]);
+                if (row_writer) dst[4] = r1;
+                const float r2 = wave_sum4_to_rows(g[8], g[9], g[10], g[11]);
+                if (row_writer) dst[8] = r2;
+                const float r3 = wave_sum4_to_rows(g[12], g[13], g[14], g[17]);
+                if (row_writer) dst[12] = r3;
+                if (__any(lowpass)) {
+                    const float r4 = wave_sum4_to_rows(g[15], g[16], 0.0f, 0.0f);
+                    if (row_writer) dst[16] = r4;
                 }
             }
         }

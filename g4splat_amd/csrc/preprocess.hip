@@ -566,9 +566,13 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     __syncthreads();
     if (!in_range) return;
 
+    // record order (blend backward): 0..14 = colour, normal, T; 15 = opacity; 16..17 = low-pass centre terms
     float g[GRAD_FLOATS];
 #pragma unroll
-    for (int i = 0; i < GRAD_FLOATS; i++) g[i] = s_sum[t * K8_SUM_STRIDE + i];
+    for (int i = 0; i < 15; i++) g[i] = s_sum[t * K8_SUM_STRIDE + i];
+    g[17] = s_sum[t * K8_SUM_STRIDE + 15];
+    g[15] = s_sum[t * K8_SUM_STRIDE + 16];
+    g[16] = s_sum[t * K8_SUM_STRIDE + 17];
     // g: [0..2] colour, [3..5] normal, [6..14] T (Tu,Tv,Tw), [15..16] mean2D, [17] opacity
     float dmean3[3] = {0, 0, 0}, dscale[2] = {0, 0};
     float4 drot = make_float4(0, 0, 0, 0);
