@@ -243,7 +243,7 @@ extern "C" int g4s_rasterizer_forward(
         int cur;
         { ProfScope ps(PF_DEPTH_SORT, stream);
           cur = radix_sort_u32_pairs(keys_a, keys_b, vals_a, vals_b, P, (uint32_t*)(geom + GL.hist),
-                                     (uint32_t*)(geom + GL.bin_total), GL.nchunks, stream); }
+                                     (uint32_t*)(geom + GL.bin_total), stream); }
         CHECK_LAUNCH("depth sort");
         const uint32_t* gidx_sorted = cur ? vals_b : vals_a;
 
@@ -286,8 +286,7 @@ extern "C" int g4s_rasterizer_forward(
             int c2;
             { ProfScope ps(PF_TILE_SORT, stream);
               c2 = radix_sort_u64_keys(ent_a, ent_b, R_binned, ENTRY_TILE_SHIFT, ENTRY_TILE_SHIFT + tile_bits,
-                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total),
-                                       (R_binned + SORT_CHUNK - 1) / SORT_CHUNK, stream); }
+                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total), stream); }
             CHECK_LAUNCH("tile partition");
             entries_ptr = c2 ? ent_b : ent_a;
             { ProfScope ps(PF_TILE_RANGES, stream); launch_tile_ranges(R_binned, entries_ptr, ranges, stream); }

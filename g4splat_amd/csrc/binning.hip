@@ -23,14 +23,14 @@ namespace g4s {
 
 template <typename K>
 __global__ void __launch_bounds__(64) radix_hist_kernel(const K* __restrict__ keys, int n, int shift,
-                                                        uint32_t* __restrict__ hist, int nchunks) {
+                                                        uint32_t* __restrict__ hist, int nchunks, int chunk_len) {
     __shared__ uint32_t h[256];
     const int chunk = (int)blockIdx.x;
     const int lane = (int)threadIdx.x;
     for (int i = lane; i < 256; i += 64) h[i] = 0;
     __syncthreads();
-    const int begin = chunk * SORT_CHUNK;
-    const int end = imin_(n, begin + SORT_CHUNK);
+    const int begin = chunk * chunk_len;
+    const int end = imin_(n, begin + chunk_len);
     for (int i = begin + lane; i < end; i += 64) {
         const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFFu;
         atomicAdd(&h[d], 1u);
@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const K* __restrict__
                                                            const uint32_t* __restrict__ vals_in,
                                                            uint32_t* __restrict__ vals_out, int n, int shift,
                                                            const uint32_t* __restrict__ hist,
-                                                           const uint32_t* __restrict__ bin_total, int nchunks) {
+                                                           const uint32_t* __restrict__ bin_total, int nchunks,
+                                                           int chunk_len) {
     __shared__ uint32_t offs[256];
     const int chunk = (int)blockIdx.x;
     const int lane = (int)threadIdx.x;
@@ -88,8 +89,8 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const K* __restrict__
         }
     }
     __syncthreads();
-    const int begin = chunk * SORT_CHUNK;
-    const int end = imin_(n, begin + SORT_CHUNK);
+    const int begin = chunk * chunk_len;
+    const int end = imin_(n, begin + chunk_len);
     const uint64_t below = lanes_below_mask();
     for (int base = begin; base < end; base += 64) {
         const int i = base + lane;
@@ -125,36 +126,37 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const K* __restrict__
 
 template <typename K, bool HAS_VAL>
 static void radix_pass(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int n, int shift, uint32_t* hist,
-                       uint32_t* bin_total, int nchunks, hipStream_t s) {
-    hipLaunchKernelGGL((radix_hist_kernel<K>), dim3(nchunks), dim3(64), 0, s, kin, n, shift, hist, nchunks);
+                       uint32_t* bin_total, hipStream_t s) {
+    const int chunk_len = sort_chunk((size_t)n), nchunks = sort_nchunks((size_t)n);
+    hipLaunchKernelGGL((radix_hist_kernel<K>), dim3(nchunks), dim3(64), 0, s, kin, n, shift, hist, nchunks, chunk_len);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, s, hist, nchunks, bin_total);
     hipLaunchKernelGGL((radix_scatter_kernel<K, HAS_VAL>), dim3(nchunks), dim3(64), 0, s, kin, kout, vin, vout, n,
-                       shift, hist, bin_total, nchunks);
+                       shift, hist, bin_total, nchunks, chunk_len);
 }
 
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
-                         uint32_t* hist, uint32_t* bin_total, int nchunks, hipStream_t s) {
+                         uint32_t* hist, uint32_t* bin_total, hipStream_t s) {
     if (n <= 0) return 0;
     int cur = 0;
     for (int shift = 0; shift < 32; shift += 8) {
         if (cur == 0)
-            radix_pass<uint32_t, true>(keys_a, keys_b, vals_a, vals_b, n, shift, hist, bin_total, nchunks, s);
+            radix_pass<uint32_t, true>(keys_a, keys_b, vals_a, vals_b, n, shift, hist, bin_total, s);
         else
-            radix_pass<uint32_t, true>(keys_b, keys_a, vals_b, vals_a, n, shift, hist, bin_total, nchunks, s);
+            radix_pass<uint32_t, true>(keys_b, keys_a, vals_b, vals_a, n, shift, hist, bin_total, s);
         cur ^= 1;
     }
     return cur;
 }
 
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
-                        uint32_t* bin_total, int nchunks, hipStream_t s) {
+                        uint32_t* bin_total, hipStream_t s) {
     if (n <= 0) return 0;
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         if (cur == 0)
-            radix_pass<uint64_t, false>(a, b, nullptr, nullptr, n, shift, hist, bin_total, nchunks, s);
+            radix_pass<uint64_t, false>(a, b, nullptr, nullptr, n, shift, hist, bin_total, s);
         else
-            radix_pass<uint64_t, false>(b, a, nullptr, nullptr, n, shift, hist, bin_total, nchunks, s);
+            radix_pass<uint64_t, false>(b, a, nullptr, nullptr, n, shift, hist, bin_total, s);
         cur ^= 1;
     }
     return cur;

@@ -20,7 +20,17 @@ constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 1
 //   q5 = conservative pixel bounding box (x0, y0, x1, y1) of the region where this splat can pass
 //        the 1/255 alpha test (empty: x0 > x1)
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
-constexpr int SORT_CHUNK = 2048;   // keys per wave-private radix chunk
+constexpr int SORT_CHUNK_MAX = 2048;  // keys per wave-private radix chunk (upper bound)
+// Chunk length for n keys: one wave per chunk; aim for ~8 waves per CU so that the per-wave serial
+// chain (chunk/64 steps) is short and the chip is full, within [256, 2048], a multiple of 64.
+inline int sort_chunk(size_t n) {
+    size_t c = (n + 2047) / 2048;  // 256 CUs x 8 waves
+    c = (c + 63) / 64 * 64;
+    if (c < 256) c = 256;
+    if (c > (size_t)SORT_CHUNK_MAX) c = SORT_CHUNK_MAX;
+    return (int)c;
+}
+inline int sort_nchunks(size_t n) { return (int)((n + sort_chunk(n) - 1) / sort_chunk(n)); }
 // Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
 // <= 65536), 31..0 Gaussian index.  Every field sits on a natural 16/32-bit boundary on purpose:
 // hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load and then drops the mask.
@@ -52,7 +62,7 @@ inline GeomLayout geom_layout(size_t P) {
     GeomLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
-    L.nchunks = (int)((P + SORT_CHUNK - 1) / SORT_CHUNK);
+    L.nchunks = sort_nchunks(P);
     L.nblocks = (int)((P + 255) / 256);
     L.rec = take(P * REC_FLOATS * 4);
     L.clamped = take(P);
@@ -77,7 +87,7 @@ inline BinLayout bin_layout(size_t R) {
     BinLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
-    L.nchunks = (int)((R + SORT_CHUNK - 1) / SORT_CHUNK);
+    L.nchunks = (int)((R + 255) / 256);  // capacity for the finest chunking of any n <= R
     L.ent_a = take((R ? R : 1) * 8);
     L.ent_b = take((R ? R : 1) * 8);
     L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
@@ -122,10 +132,10 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
 // Stable LSD radix sort.  32-bit keys with 32-bit payload (ping-pong a<->b, result index
 // returned: 0 = in *_a, 1 = in *_b) over bits [0,32).
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
-                         uint32_t* hist, uint32_t* bin_total, int nchunks, hipStream_t s);
+                         uint32_t* hist, uint32_t* bin_total, hipStream_t s);
 // 64-bit keys-only over bits [begin_bit, end_bit).
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
-                        uint32_t* bin_total, int nchunks, hipStream_t s);
+                        uint32_t* bin_total, hipStream_t s);
 
 // Exclusive scan (in depth order) of tiles_touched; total written to *total (device).
 // total[0] = instances binned, total[1] = sum of ref_block_sums (the reference's num_rendered).

@@ -26,7 +26,7 @@ static KnnLayout knn_layout(size_t P) {
     KnnLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
-    L.nchunks = (int)((P + SORT_CHUNK - 1) / SORT_CHUNK);
+    L.nchunks = sort_nchunks(P);
     L.nboxes = (int)((P + BOX - 1) / BOX);
     L.nparts = (int)((P + 1023) / 1024);
     L.keys_a = take(P * 4); L.keys_b = take(P * 4); L.vals_a = take(P * 4); L.vals_b = take(P * 4);
@@ -207,7 +207,7 @@ extern "C" int g4s_knn_launch_internal(int P, const float* points, float* meanDi
     hipLaunchKernelGGL(knn_bbox_final_kernel, dim3(1), dim3(1024), 0, s, L.nparts, partial, bbox);
     hipLaunchKernelGGL(knn_morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, bbox, keys_a, vals_a);
     const int cur = radix_sort_u32_pairs(keys_a, keys_b, vals_a, vals_b, P, (uint32_t*)(w + L.hist),
-                                         (uint32_t*)(w + L.bin_total), L.nchunks, s);
+                                         (uint32_t*)(w + L.bin_total), s);
     const uint32_t* order = cur ? vals_b : vals_a;
     hipLaunchKernelGGL(knn_gather_boxes_kernel, dim3(L.nboxes), dim3(1024), 0, s, P, points, order, sorted, boxes);
     hipLaunchKernelGGL(knn_mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, sorted, boxes, L.nboxes,
