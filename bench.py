@@ -91,7 +91,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("G4S_FORCE_DIST"):  # G4S_FORCE_DIST: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -109,6 +109,25 @@ def main():
     dL_dcolor = torch.randn((3, H, W), device=device, generator=g)
     dL_dothers = torch.randn((7, H, W), device=device, generator=g)
 
+    # one persistent flat fp32 bucket holds the parameter gradients of this rank's view (xyz, SH,
+    # opacity, scale, rotation = 58 floats per Gaussian at SH degree 3); the backward writes straight into views of
+    # it (`out=`), so the exchange is ONE RCCL all-reduce over xGMI plus the small densification side channel
+    # (per-view ||grad_means2D|| and visibility summed, radii max-reduced).  Persistent buffers also keep torch's
+    # caching allocator out of the timed region (no record_stream-deferred frees of 350 MB blocks).
+    grad_out = side = rmax = bucket = None
+    if dist is not None:
+        M = int(dev["sh"].shape[1])
+        shapes = [("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 2)),
+                  ("dL_drotations", (P, 4))]
+        offs, o = [], 0
+        for _n, shp in shapes:
+            offs.append(o)
+            o += (int(np.prod(shp)) + 63) // 64 * 64  # 256-B aligned views
+        bucket = torch.zeros(o, device=device)
+        grad_out = {n: bucket[b:b + int(np.prod(shp))].view(shp) for (n, shp), b in zip(shapes, offs)}
+        side = torch.zeros((P, 2), device=device)
+        rmax = torch.zeros((P,), dtype=torch.int32, device=device)
+
     def step(i):
         cam = dcams[(rank + i * world) % len(dcams)]
         fw = _C.rasterize_gaussians(bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0,
@@ -118,15 +137,14 @@ def main():
         grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
                                                 1.0, empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"],
                                                 dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
-                                                img, False)
+                                                img, False, out=grad_out)
         if dist is not None:
-            # SUM of the parameter gradients (xyz, SH, opacity, scale, rotation = 58 floats per
-            # Gaussian) + densification side channel (per-view ||grad_means2D||, visibility count, max radii)
-            gm2, _gc, gop, gm3, _gt, gsh, gsc, grot = grads
-            stats = torch.stack([gm2[:, :2].norm(dim=1), (radii > 0).float()], 1)
-            works = [dist.all_reduce(t, async_op=True) for t in (gm3, gsh, gop, gsc, grot, stats)]
-            rmax = radii.clone()
-            works.append(dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True))
+            gm2 = grads[0]
+            torch.linalg.vector_norm(gm2[:, :2], dim=1, out=side[:, 0])
+            side[:, 1] = radii > 0
+            rmax.copy_(radii)
+            works = [dist.all_reduce(bucket, async_op=True), dist.all_reduce(side, async_op=True),
+                     dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True)]
             for w_ in works:
                 w_.wait()
         return R, radii

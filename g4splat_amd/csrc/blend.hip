@@ -161,17 +161,22 @@ void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
 constexpr int BWD_BATCH = 64;
 
 struct BwdPixel {
-    // constants
-    float T_final, final_D, final_D2, bg_dot;
+    // constants.  The distortion terms only ever appear multiplied by dL_dreg, so they are kept as
+    //   A2 = (1 - T_final) dL_dreg,  D2 = 2 final_D dL_dreg,  C2 = final_D2 dL_dreg
+    // (backward.cu:342-359: dL_dweight = m^2 A2 - m D2 + C2,  dL_dmd = w (2 m A2 - D2)),
+    // and the background term (backward.cu:384-387) as nTfbg = -T_final <bg, dL_dpix>.
+    float A2, D2, C2, nTfbg;
     uint32_t last_c, median_c;
-    float dpx0, dpx1, dpx2, dL_ddepth, dL_daccum, dL_dreg, dn0, dn1, dn2, dL_dmedian;
+    float dpx0, dpx1, dpx2, dL_ddepth, dL_daccum, dn0, dn1, dn2, dL_dmedian;
     // running state (back to front)
     float T, last_alpha, last_v, V_rec, last_dL_dT;
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-__global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
+// waves_per_eu(3): 168 VGPRs instead of the 171 the allocator would take -> 3 resident waves per SIMD instead of 2
+// (two 4-byte spills land in the per-batch prologue, not in the entry loop); measured 1.86 -> 1.51 ms on S3.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) blend_bwd_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[REC_QUADS - 1][BWD_BATCH];  // the box quad is not needed here
     __shared__ uint32_t s_slot[BWD_BATCH];
 
@@ -194,11 +199,12 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
         const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
         BwdPixel& x = p[q];
         x = BwdPixel{};
+        float T_final = 0, final_D = 0, final_D2 = 0, dL_dreg = 0;
         if (px < a.W && py < a.H) {
             const size_t pix_id = (size_t)a.W * py + px;
-            x.T_final = a.final_T[pix_id];
-            x.final_D = a.final_T[pix_id + N];
-            x.final_D2 = a.final_T[pix_id + 2 * N];
+            T_final = a.final_T[pix_id];
+            final_D = a.final_T[pix_id + N];
+            final_D2 = a.final_T[pix_id + 2 * N];
             x.last_c = a.n_contrib[pix_id];
             x.median_c = a.n_contrib[pix_id + N];
             x.dpx0 = a.dL_dpix[pix_id];
@@ -210,14 +216,17 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
             x.dn1 = a.dL_depths[pix_id + 3 * N];
             x.dn2 = a.dL_depths[pix_id + 4 * N];
             x.dL_dmedian = a.dL_depths[pix_id + 5 * N];
-            x.dL_dreg = a.dL_depths[pix_id + 6 * N];
+            dL_dreg = a.dL_depths[pix_id + 6 * N];
         }
-        x.bg_dot = (bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2;
-        x.T = x.T_final;
+        x.A2 = (1 - T_final) * dL_dreg;
+        x.D2 = 2.0f * final_D * dL_dreg;
+        x.C2 = final_D2 * dL_dreg;
+        x.nTfbg = -T_final * ((bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2);
+        x.T = T_final;
         max_last = max(max_last, x.last_c);  // pixels outside the image keep last_c = 0: never active
     }
     const float mscale = FAR_N / (FAR_N - NEAR_N);
-    const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
+    const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m = mscale - dmd_k / depth, dm/ddepth = dmd_k / depth^2
     const bool row_writer = (lane & 15) == 15;
     const int row = lane >> 4;
 
@@ -288,7 +297,7 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
                     const float v = fmaf(q4.y, x.dpx0, fmaf(q4.z, x.dpx1, q4.w * x.dpx2)) +
                                     fmaf(c_d, x.dL_ddepth, x.dL_daccum) +
                                     fmaf(q1.x, x.dn0, fmaf(q1.y, x.dn1, q1.z * x.dn2));
-                    x.V_rec = fmaf(x.last_alpha, x.last_v, (1.f - x.last_alpha) * x.V_rec);
+                    x.V_rec = fmaf(x.last_alpha, x.last_v - x.V_rec, x.V_rec);  // a v + (1 - a) V_rec
                     x.last_v = v;
                     float dL_dalpha = v - x.V_rec;
                     g[0] = fmaf(w, x.dpx0, g[0]);
@@ -298,20 +307,20 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
                     g[4] = fmaf(w, x.dn1, g[4]);
                     g[5] = fmaf(w, x.dn2, g[5]);
 
-                    const float final_A = 1 - x.T_final;
                     const float inv_cd = fast_rcp(c_d);
-                    const float m_d = mscale * (1 - NEAR_N * inv_cd);
+                    const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
                     float dL_dz = (pos + 1 == x.median_c) ? x.dL_dmedian : 0.0f;
-                    const float dL_dweight = (x.final_D2 + m_d * m_d * final_A - 2 * m_d * x.final_D) * x.dL_dreg;
-                    dL_dalpha += dL_dweight - x.last_dL_dT;
-                    x.last_dL_dT = fmaf(dL_dweight, alpha, (1 - alpha) * x.last_dL_dT);
-                    const float dL_dmd = 2.0f * w * (m_d * final_A - x.final_D) * x.dL_dreg;
+                    const float dL_dweight = fmaf(m_d, fmaf(m_d, x.A2, -x.D2), x.C2);
+                    const float dwt = dL_dweight - x.last_dL_dT;
+                    dL_dalpha += dwt;
+                    x.last_dL_dT = fmaf(alpha, dwt, x.last_dL_dT);  // a dL_dweight + (1 - a) last_dL_dT
+                    const float dL_dmd = w * fmaf(m_d + m_d, x.A2, -x.D2);
                     dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
 
                     dL_dalpha *= T;
                     x.last_alpha = alpha;
-                    dL_dalpha = fmaf(-x.T_final * inv1ma, x.bg_dot, dL_dalpha);
+                    dL_dalpha = fmaf(x.nTfbg, inv1ma, dL_dalpha);
                     const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
 
@@ -346,25 +355,23 @@ __global__ void __launch_bounds__(64) blend_bwd_kernel(BlendBwdArgs a) {
                     g[17] = fmaf(G, dL_dalpha, g[17]);
                 }
             }
-            // 256 pixels -> 1: the four pixels of a lane were summed in registers above, the 64 lanes
-            // are summed four terms at a time; row k of sum_i then holds term 4 i + k.
-            float* dst = a.grad_inst + (size_t)s_slot[j] * GRAD_STRIDE + row;
+            // 256 pixels -> 1: the four pixels of a lane were summed in registers above; the 64 lanes are
+            // summed sixteen terms at a time, after which row k holds terms 4k..4k+3 and its last lane writes
+            // them with one 16-byte store.
             // Record layout: floats 0..14 = terms 0..14 (colour, normal, T), 15 = opacity term, 16..17 = the
             // low-pass centre terms -- those are non-zero only when some pixel took the 2-D filter branch
             // (rare for splats wider than a pixel), so their group is reduced and stored only then; the
             // record buffer is pre-cleared.
             if (any_active && !(a.dbg & 1)) {
-                const float r0 = wave_sum4_to_rows(g[0], g[1], g[2], g[3]);
-                if (row_writer) dst[0] = r0;
-                const float r1 = wave_sum4_to_rows(g[4], g[5], g[6], g[7]);
-                if (row_writer) dst[4] = r1;
-                const float r2 = wave_sum4_to_rows(g[8], g[9], g[10], g[11]);
-                if (row_writer) dst[8] = r2;
-                const float r3 = wave_sum4_to_rows(g[12], g[13], g[14], g[17]);
-                if (row_writer) dst[12] = r3;
+                float* rec = a.grad_inst + (size_t)s_slot[j] * GRAD_STRIDE;
+                float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],
+                               g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[17]};
+                float r[4];
+                wave_sum16_to_rows(t, r);
+                if (row_writer) *reinterpret_cast<float4*>(rec + 4 * row) = make_float4(r[0], r[1], r[2], r[3]);
                 if (__any(lowpass)) {
                     const float r4 = wave_sum4_to_rows(g[15], g[16], 0.0f, 0.0f);
-                    if (row_writer) dst[16] = r4;
+                    if (row_writer) rec[16 + row] = r4;
                 }
             }
         }

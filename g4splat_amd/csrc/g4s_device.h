@@ -73,6 +73,43 @@ __device__ __forceinline__ float wave_sum4_to_rows(float v0, float v1, float v2,
     return r;
 }
 
+// Sixteen values at once: on return lane l of row k = l/16 holds, in out[i], the wave sum of v[4k+i]
+// (valid in every lane of the row), so the lane that writes a row stores four consecutive terms with
+// one 16-byte store.  All swaps of a stage share one s_nop and the four DPP chains interleave, so
+// the 63 additions per term cost 8+4 swaps, 12 adds and 16 DPP adds for all sixteen terms.
+__device__ __forceinline__ void wave_sum16_to_rows(float (&v)[16], float (&out)[4]) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\t"
+        "v_permlane32_swap_b32 %1, %9\n\t"
+        "v_permlane32_swap_b32 %2, %10\n\t"
+        "v_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\t"
+        "v_permlane32_swap_b32 %5, %13\n\t"
+        "v_permlane32_swap_b32 %6, %14\n\t"
+        "v_permlane32_swap_b32 %7, %15"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+    // s[j]: lanes 0-31 = partial sums of v[j], lanes 32-63 = partial sums of v[8+j]
+    float s0 = v[0] + v[8], s1 = v[1] + v[9], s2 = v[2] + v[10], s3 = v[3] + v[11];
+    float s4 = v[4] + v[12], s5 = v[5] + v[13], s6 = v[6] + v[14], s7 = v[7] + v[15];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %4\n\t"
+        "v_permlane16_swap_b32 %1, %5\n\t"
+        "v_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane16_swap_b32 %3, %7"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7));
+    // rows 0..3 of r_i: partial sums of v[i], v[4+i], v[8+i], v[12+i]
+    float r0 = s0 + s4, r1 = s1 + s5, r2 = s2 + s6, r3 = s3 + s7;
+    r0 += dpp_f32<0xB1>(r0); r1 += dpp_f32<0xB1>(r1); r2 += dpp_f32<0xB1>(r2); r3 += dpp_f32<0xB1>(r3);
+    r0 += dpp_f32<0x4E>(r0); r1 += dpp_f32<0x4E>(r1); r2 += dpp_f32<0x4E>(r2); r3 += dpp_f32<0x4E>(r3);
+    r0 += dpp_f32<0x124>(r0); r1 += dpp_f32<0x124>(r1); r2 += dpp_f32<0x124>(r2); r3 += dpp_f32<0x124>(r3);
+    r0 += dpp_f32<0x128>(r0); r1 += dpp_f32<0x128>(r1); r2 += dpp_f32<0x128>(r2); r3 += dpp_f32<0x128>(r3);
+    // row k now holds the sums of v[4k] (r0), v[4k+1] (r1), v[4k+2] (r2), v[4k+3] (r3)
+    out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_sum_to_lane63(v), 63);
 }

@@ -106,7 +106,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                 dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                 out=None):
+    """`out` (extension over the reference): optional dict name -> preallocated float32 tensor for any of the
+    returned gradients, e.g. views of a persistent all-reduce bucket (parallel.py); the library writes every
+    element of them, so no packing copy is needed before the collective."""
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
                     ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
@@ -119,16 +123,32 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dev = means3D.device
     with torch.cuda.device(dev):
         fopt = dict(dtype=torch.float32, device=dev)
-        make = torch.zeros if P == 0 else torch.empty  # the library writes every element when P > 0
-        dL_dmeans3D = make((P, 3), **fopt)
-        dL_dmeans2D = make((P, 3), **fopt)
-        dL_dcolors = make((P, NUM_CHANNELS), **fopt)
+        alloc = torch.zeros if P == 0 else torch.empty  # the library writes every element when P > 0
+        given = dict(out) if out else {}
+
+        def make(shape, name=None, align=4, **kw):
+            t = given.pop(name, None)
+            if t is None:
+                return alloc(shape, **kw)
+            if (tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or t.device != dev
+                    or not t.is_contiguous() or (t.numel() and t.data_ptr() % align)):
+                raise RuntimeError(f"out['{name}'] must be a contiguous float32 {tuple(shape)} tensor on {dev}, "
+                                   f"{align}-byte aligned")
+            if P == 0:
+                t.zero_()
+            return t
+
+        dL_dmeans3D = make((P, 3), "dL_dmeans3D", **fopt)
+        dL_dmeans2D = make((P, 3), "dL_dmeans2D", **fopt)
+        dL_dcolors = make((P, NUM_CHANNELS), "dL_dcolors", **fopt)
         dL_dnormal = make((P, 3), **fopt)
-        dL_dopacity = make((P, 1), **fopt)
-        dL_dtransMat = make((P, 9), **fopt)
-        dL_dsh = make((P, M, 3), **fopt)
-        dL_dscales = make((P, 2), **fopt)
-        dL_drotations = make((P, 4), **fopt)
+        dL_dopacity = make((P, 1), "dL_dopacity", **fopt)
+        dL_dtransMat = make((P, 9), "dL_dtransMat", **fopt)
+        dL_dsh = make((P, M, 3), "dL_dsh", **fopt)
+        dL_dscales = make((P, 2), "dL_dscales", 8, **fopt)
+        dL_drotations = make((P, 4), "dL_drotations", 16, **fopt)
+        if given:
+            raise RuntimeError(f"unknown out= entries: {sorted(given)}")
         if P != 0:
             ws_bytes = lib.g4s_rasterizer_backward_workspace(P, int(R))
             workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

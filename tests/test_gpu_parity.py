@@ -43,39 +43,6 @@ def check_lists_against_oracle(st, orc, oracle_mod):
     olist, orng = orc.state("point_list"), orc.state("ranges")
     flags = oracle_mod.instance_flags(orc)
     ent = st["entries"]
-    assert np.array_equal((ent >> np.uint64(48)).astype(np.int64), np.repeat(np.arange(len(st["ranges"])),
-                                                                            st["ranges"][:, 1] - st["ranges"][:, 0]))
-    kept = 0
-    for tile, hl in enumerate(hip_tile_lists(st)):
-        ol = olist[orng[tile, 0]:orng[tile, 1]]
-        fl = flags[orng[tile, 0]:orng[tile, 1]]
-        # subsequence check with a two-pointer walk
-        pos = np.searchsorted(np.cumsum(np.ones(len(ol), np.int64)), 0)  # noqa: F841 (keeps numpy imported)
-        it = 0
-        taken = np.zeros(len(ol), bool)
-        for g in hl:
-            while it < len(ol) and ol[it] != g:
-                it += 1
-            assert it < len(ol), f"tile {tile}: HIP list is not a subsequence of the reference list"
-            taken[it] = True
-            it += 1
-        assert not np.any(fl.astype(bool) & ~taken), f"tile {tile}: a contributing instance was culled"
-        kept += len(hl)
-    return kept, len(olist)
-
-
-def hip_tile_lists(st):
-    ent, rng = st["entries"], st["ranges"]
-    idx = (ent & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    return [idx[a:b] for a, b in rng]
-
-
-def check_lists_against_oracle(st, orc, oracle_mod):
-    """The HIP per-tile lists must be the oracle's lists (tile, depth, index order) minus only
-    instances that cannot pass the alpha test at any pixel of the tile (alpha-cutoff culling)."""
-    olist, orng = orc.state("point_list"), orc.state("ranges")
-    flags = oracle_mod.instance_flags(orc)
-    ent = st["entries"]
     counts = (st["ranges"][:, 1] - st["ranges"][:, 0]).astype(np.int64)
     assert np.array_equal((ent >> np.uint64(48)).astype(np.int64), np.repeat(np.arange(len(counts)), counts))
     kept = 0
@@ -209,6 +176,42 @@ def test_backward_is_deterministic(hip_lib):
     b = run_hip(inp, g)
     for k in a["grads"]:
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k])
+
+
+def test_backward_out_views_of_a_bucket(hip_lib):
+    """`out=`: gradients written straight into views of one flat buffer (the all-reduce bucket of
+    parallel.py) are bit-identical to the separately allocated ones; bad views are refused."""
+    import torch
+    from g4splat_amd.diff_surfel_rasterization import _C
+    inp = scene_inputs(P=3001, W=200, H=120, seed=5)  # odd P: views need the padding to stay aligned
+    gr = cotangents(inp["H"], inp["W"])
+    base = run_hip(inp, gr)
+    P, M = 3001, inp["sh"].shape[1]
+    shapes = [("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 2)),
+              ("dL_drotations", (P, 4))]
+    offs, o = [], 0
+    for _n, shp in shapes:
+        offs.append(o)
+        o += (int(np.prod(shp)) + 63) // 64 * 64
+    bucket = torch.full((o,), float("nan"), device="cuda:0")
+    out = {n: bucket[b:b + int(np.prod(shp))].view(shp) for (n, shp), b in zip(shapes, offs)}
+    a = base["args"]
+    t = lambda x: torch.as_tensor(x, device="cuda:0")
+    call = lambda out_: _C.rasterize_gaussians_backward(
+        a["bg"], a["means3D"], t(base["radii"]), a["colors"], a["scales"], a["rotations"], 1.0, a["transMat"], a["view"],
+        a["proj"], inp["tanfovx"], inp["tanfovy"], t(gr[0]), t(gr[1]), a["sh"], inp["D"], a["campos"], base["geom"],
+        base["R"], base["binning"], base["img"], False, out=out_)
+    g = call(out)
+    assert g[3].data_ptr() == out["dL_dmeans3D"].data_ptr() and g[5].data_ptr() == out["dL_dsh"].data_ptr()
+    for name, key in (("dL_dmeans3D", "means3D"), ("dL_dsh", "sh"), ("dL_dopacity", "opacity"),
+                      ("dL_dscales", "scales"), ("dL_drotations", "rotations")):
+        assert np.array_equal(out[name].cpu().numpy(), base["grads"][key]), name
+    with pytest.raises(RuntimeError):
+        call({"dL_drotations": bucket[1:1 + 4 * P].view(P, 4)})  # 4-byte offset: not 16-byte aligned
+    with pytest.raises(RuntimeError):
+        call({"dL_dsh": torch.empty((P, M, 3), device="cuda:0", dtype=torch.float64)})
+    with pytest.raises(RuntimeError):
+        call({"nonsense": bucket})
 
 
 def test_mark_visible(hip_lib, oracle_mod):
