@@ -48,17 +48,21 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
 
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int n = (int)(r1 - r0);
-    bool done = !inside;
 
-    float T = 1.0f;
+    // Tt = running transmittance while the pixel is live, 0 once it is saturated (forward.cu:327,399 `done`) or
+    // when it lies outside the image: a dead pixel then fails `test_T >= 1e-4` by itself, so the loop needs no
+    // per-lane `done` predicate, and "all 64 pixels dead" is one v_cmp of Tt against 0.  T_done keeps the
+    // transmittance a saturated pixel had when it stopped (the value the reference leaves in T).
+    float Tt = inside ? 1.0f : 0.0f, T_done = 1.0f;
     uint32_t last_contributor = 0, median_contributor = 0;
     float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0;
     float Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
     const float mscale = FAR_N / (FAR_N - NEAR_N);
+    const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m(depth) = mscale - dmd_k / depth
 
     for (int b0 = 0; b0 < n; b0 += FWD_BATCH) {
         // end if the entire tile is saturated (forward.cu:327)
-        if (__syncthreads_count(done) == 256) break;
+        if (__syncthreads_count(Tt == 0.0f) == 256) break;
         const int m = imin_(FWD_BATCH, n - b0);
         if ((int)threadIdx.x < m) {
             const uint64_t e = a.entries[r0 + b0 + threadIdx.x];
@@ -68,7 +72,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
         }
         if (threadIdx.x < (FWD_BATCH / 64) * 4) (&s_hit[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
-        if (!__all(done)) {
+        if (__ballot(Tt != 0.0f) != 0ull) {
         // Each group of 64 staged entries is first filtered against this wave's quadrant with one
         // box test per lane + a ballot; only entries whose alpha-cutoff box touches the quadrant are
         // visited (scalar bit scan), so a rejected entry costs ~1/64 of a loop iteration.
@@ -77,50 +81,52 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
             const bool rel = jl < m && !quad_misses_box(s_rec[5][jl < FWD_BATCH ? jl : 0], qxf, qyf);
             uint64_t todo = __ballot(rel);
             uint64_t hit = 0;  // wave-uniform: entries of this group blended by some pixel of this quadrant
+            bool live = true;  // wave-uniform: some pixel of the quadrant is not saturated yet
             while (todo) {
-                if (__all(done)) break;
                 const int bit = (int)__builtin_ctzll(todo);
                 const int j = g0 + bit;
                 todo &= todo - 1;
-                bool blended = false;
-                if (!done) {
                 // `contributor` of the reference = 1-based list position (forward.cu:349)
                 const uint32_t contributor = (uint32_t)(b0 + j + 1);
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
                 PairEval e;
                 if (eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e)) {
-                const float alpha = e.alpha, depth = e.depth;
-                const float test_T = T * (1 - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                } else {
-                blended = true;
-                const float w = alpha * T;
-                const float A = 1 - T;
-                const float md = mscale * (1 - NEAR_N * __builtin_amdgcn_rcpf(depth));
-                distortion += (md * md * A + M2 - 2 * md * M1) * w;
-                Dd = fmaf(depth, w, Dd);
-                M1 = fmaf(md, w, M1);
-                M2 = fmaf(md * md, w, M2);
-                if (T > 0.5f) {
-                    median_depth = depth;
-                    median_contributor = contributor;
+                    const float alpha = e.alpha, depth = e.depth;
+                    const float T = Tt;
+                    const float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) {
+                        if (T != 0.0f) T_done = T;
+                        Tt = 0.0f;
+                    } else {
+                        const float w = alpha * T;
+                        const float A = 1 - T;
+                        const float md = fmaf(-dmd_k, __builtin_amdgcn_rcpf(depth), mscale);
+                        const float md2 = md * md;
+                        distortion = fmaf(fmaf(-(md + md), M1, fmaf(md2, A, M2)), w, distortion);
+                        Dd = fmaf(depth, w, Dd);
+                        M1 = fmaf(md, w, M1);
+                        M2 = fmaf(md2, w, M2);
+                        if (T > 0.5f) {
+                            median_depth = depth;
+                            median_contributor = contributor;
+                        }
+                        N0 = fmaf(q1.x, w, N0);
+                        N1 = fmaf(q1.y, w, N1);
+                        N2 = fmaf(q1.z, w, N2);
+                        C0 = fmaf(q4.y, w, C0);
+                        C1 = fmaf(q4.z, w, C1);
+                        C2 = fmaf(q4.w, w, C2);
+                        Tt = test_T;
+                        last_contributor = contributor;
+                    }
                 }
-                N0 = fmaf(q1.x, w, N0);
-                N1 = fmaf(q1.y, w, N1);
-                N2 = fmaf(q1.z, w, N2);
-                C0 = fmaf(q4.y, w, C0);
-                C1 = fmaf(q4.z, w, C1);
-                C2 = fmaf(q4.w, w, C2);
-                T = test_T;
-                last_contributor = contributor;
-                }
-                }
-                }
-                if (__any(blended)) hit |= 1ull << bit;
+                // blended by some pixel <=> some pixel's last_contributor is this entry
+                if (__ballot(last_contributor == contributor) != 0ull) hit |= 1ull << bit;
+                live = __ballot(Tt != 0.0f) != 0ull;
+                if (!live) break;
             }
             if (lane == 0 && hit) s_hit[g0 >> 6][wv] = hit;
-            if (__all(done)) break;
+            if (!live) break;
         }
         }
         // contribution mask for the backward: one byte per staged entry, bit q = quadrant q blended it
@@ -132,6 +138,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
             if (nib) a.qhit[r0 + b0 + threadIdx.x] = (uint8_t)nib;
         }
     }
+    const float T = Tt != 0.0f ? Tt : T_done;
     if (inside) {
         a.final_T[pix_id] = T;
         a.final_T[pix_id + N] = M1;
@@ -279,10 +286,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 BwdPixel& x = p[q];
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
-                bool act = pos < x.last_c && !(a.dbg & 4);
+                bool act = pos < x.last_c;
                 if (act)
                     act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
-                if (a.dbg & 2) { g[0] += act ? e.G : 0.0f; act = false; }
                 if (!__any(act)) continue;
                 any_active = true;
                 if (act) {

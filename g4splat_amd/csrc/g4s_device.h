@@ -271,13 +271,17 @@ __device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float 
     e.sy = ppy / ppz;
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
 #endif
-    const float rho = fminf(e.rho3d, e.rho2d);
-    e.depth = (e.rho3d <= e.rho2d) ? fmaf(e.sx, Twx, e.sy * Twy) + Twz : Twz;
+    // rho = min(rho3d, rho2d) and the depth select share one compare.  (NaN rho3d -- 0 * inf when p.z is
+    // denormal -- takes the rho2d side in both, like fminf.)
+    const bool in3d = e.rho3d <= e.rho2d;
+    const float rho = in3d ? e.rho3d : e.rho2d;
+    e.depth = in3d ? fmaf(e.sx, Twx, e.sy * Twy) + Twz : Twz;
     if (e.depth < NEAR_N) return false;
-    const float power = -0.5f * rho;
-    if (power > 0.0f) return false;
-    // exp(power) as one v_exp_f32: power in [-5.6, 0] for anything that can pass, error ~3e-7 relative
-    e.G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+    // forward.cu:383-385 `power = -0.5 rho; if (power > 0) continue;` can never fire (rho is a sum of squares),
+    // and exp(power) = exp2(rho * (-0.5 log2 e)): scaling by -0.5 is exact, so folding it into the constant
+    // rounds exactly like (-0.5f * rho) * log2e.  One v_exp_f32: rho in [0, 11.2] for anything that can pass,
+    // error ~3e-7 relative.
+    e.G = __builtin_amdgcn_exp2f(rho * (-0.5f * 1.4426950408889634f));
     e.alpha = fminf(0.99f, opa * e.G);
     if (e.alpha < 1.0f / 255.0f) return false;
     return true;
