@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             float g[GRAD_STRIDE];
 #pragma unroll
             for (int i = 0; i < GRAD_STRIDE; i++) g[i] = 0.0f;
-            bool any_active = false, lowpass = false;
+            bool lowpass = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!((qm >> q) & 1u)) continue;  // scalar branch
@@ -289,8 +289,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 bool act = pos < x.last_c;
                 if (act)
                     act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
-                if (!__any(act)) continue;
-                any_active = true;
+                // (qhit is exact, so some pixel of the quadrant is active; no wave vote needed)
                 if (act) {
                     const float G = e.G, alpha = e.alpha, c_d = e.depth;
                     const float inv1ma = fast_rcp(1.f - alpha);
@@ -334,7 +333,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                         const float mG = dL_dG * -G;
                         const float dL_dsx = fmaf(mG, e.sx, dL_dz * q3.z);
                         const float dL_dsy = fmaf(mG, e.sy, dL_dz * q3.w);
-                        const float inv_pz = fast_rcp(e.pz);
+                        const float inv_pz = e.inv_pz;  // the v_rcp_f32 of eval_pair
                         const float dpx_ = dL_dsx * inv_pz, dpy_ = dL_dsy * inv_pz;
                         const float dpz_ = -fmaf(dpx_, e.sx, dpy_ * e.sy);
                         // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
@@ -366,19 +365,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             // them with one 16-byte store.
             // Record layout: floats 0..14 = terms 0..14 (colour, normal, T), 15 = opacity term, 16..17 = the
             // low-pass centre terms -- those are non-zero only when some pixel took the 2-D filter branch
-            // (rare for splats wider than a pixel), so their group is reduced and stored only then; the
-            // record buffer is pre-cleared.
-            if (any_active && !(a.dbg & 1)) {
-                float* rec = a.grad_inst + (size_t)s_slot[j] * GRAD_STRIDE;
+            // (rare for splats wider than a pixel), so their group is reduced and stored only then.  The record
+            // buffer is not cleared: rec_flag[slot] (pre-cleared, one byte) says which parts are valid.
+            if (!(a.dbg & 1)) {
+                const uint32_t slot = s_slot[j];
+                float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
                 float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],
                                g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[17]};
                 float r[4];
                 wave_sum16_to_rows(t, r);
                 if (row_writer) *reinterpret_cast<float4*>(rec + 4 * row) = make_float4(r[0], r[1], r[2], r[3]);
-                if (__any(lowpass)) {
+                const bool lp = __any(lowpass);
+                if (lp) {
                     const float r4 = wave_sum4_to_rows(g[15], g[16], 0.0f, 0.0f);
                     if (row_writer) rec[16 + row] = r4;
                 }
+                if (lane == 0) a.rec_flag[slot] = lp ? 3 : 1;
             }
         }
     }

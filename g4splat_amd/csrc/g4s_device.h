@@ -231,7 +231,7 @@ constexpr float FILTER_INV_SQUARE = 2.0f;  // auxiliary.h:39
 // Ray/splat evaluation for one (pixel, splat) pair -- forward.cu:351-383 / backward.cu:267-301.
 // The fmaf placement is the contract shared with the oracle (oracle/surfel_oracle.c eval_pair).
 struct PairEval {
-    float sx, sy, pz, kx, ky, kz, lx, ly, lz, rho3d, rho2d, depth, G, alpha, dx, dy;
+    float sx, sy, pz, inv_pz, kx, ky, kz, lx, ly, lz, rho3d, rho2d, depth, G, alpha, dx, dy;
 };
 __device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float cy, float Tux, float Tuy, float Tuz,
                                           float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz,
@@ -257,6 +257,7 @@ __device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float 
     // oracle's and the values differ from it by ~1e-7 relative.
     {
         const float inv = __builtin_amdgcn_rcpf(ppz);
+        e.inv_pz = inv;
         e.sx = ppx * inv;
         e.sy = ppy * inv;
         e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
@@ -267,6 +268,7 @@ __device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float 
         }
     }
 #else
+    e.inv_pz = __builtin_amdgcn_rcpf(ppz);
     e.sx = ppx / ppz;
     e.sy = ppy / ppz;
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);

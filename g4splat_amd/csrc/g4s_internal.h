@@ -180,7 +180,8 @@ struct BlendBwdArgs {
     const uint8_t* qhit;
     const float* dL_dpix;
     const float* dL_depths;
-    float* grad_inst;  // R x GRAD_STRIDE
+    float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
+    uint8_t* rec_flag; // R bytes, pre-cleared: bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
     int dbg;           // experiments only (G4S_BWD_DBG): 1 skip reduction, 2 skip gradient math, 4 skip evaluation
 };
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
@@ -193,6 +194,7 @@ struct PreprocessBwdArgs {
     const float* rec;
     const uint8_t* clamped;
     const float* grad_inst;
+    const uint8_t* rec_flag;
     float* gsum;  // P x 18 folded gradient terms (workspace)
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
     int dbg_skip;   // bring-up/experiments only (G4S_K8_SKIP): 1 = skip fold, 2 = skip SH, 4 = skip small outputs

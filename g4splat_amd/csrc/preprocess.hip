@@ -467,18 +467,23 @@ __global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) 
             // records 0..15 (terms 0..15, 16 records x 4 quads) and records 0..63 (terms 16..17)
             float4 accA[U];
             float2 accB[U];
+            uint8_t fA[U], fB[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
                 const float2* base2 = reinterpret_cast<const float2*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
                 accA[u] = base4[(size_t)((uint32_t)kk < cn[u] ? kk : 0) * (GRAD_STRIDE / 4) + c];
                 accB[u] = base2[(size_t)((uint32_t)lane < cn[u] ? lane : 0) * (GRAD_STRIDE / 2) + 8];
+                fA[u] = a.rec_flag[of[u] + ((uint32_t)kk < cn[u] ? kk : 0)];
+                fB[u] = a.rec_flag[of[u] + ((uint32_t)lane < cn[u] ? lane : 0)];
             }
+            // records the blend backward never wrote hold garbage (possibly NaN): select, do not multiply
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const float ma = (uint32_t)kk < cn[u] ? 1.0f : 0.0f, mb = (uint32_t)lane < cn[u] ? 1.0f : 0.0f;
-                accA[u].x *= ma; accA[u].y *= ma; accA[u].z *= ma; accA[u].w *= ma;
-                accB[u].x *= mb; accB[u].y *= mb;
+                const bool ma = (uint32_t)kk < cn[u] && (fA[u] & 1), mb = (uint32_t)lane < cn[u] && (fB[u] & 2);
+                accA[u].x = ma ? accA[u].x : 0.0f; accA[u].y = ma ? accA[u].y : 0.0f;
+                accA[u].z = ma ? accA[u].z : 0.0f; accA[u].w = ma ? accA[u].w : 0.0f;
+                accB[u].x = mb ? accB[u].x : 0.0f; accB[u].y = mb ? accB[u].y : 0.0f;
             }
             // long runs (rare): the remaining records, in ascending order
 #pragma unroll
@@ -490,28 +495,32 @@ __global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) 
                 // lane, so a Gaussian with thousands of instances is not a serial chain of round trips
                 for (uint32_t k0 = 16; k0 < cn[u]; k0 += 128) {
                     float4 x[8];
+                    uint8_t f[8];
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const uint32_t k = k0 + 16 * i + kk;
                         x[i] = base4[(size_t)(k < cn[u] ? k : 0) * (GRAD_STRIDE / 4) + c];
+                        f[i] = a.rec_flag[of[u] + (k < cn[u] ? k : 0)];
                     }
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
-                        const float msk = (k0 + 16 * i + kk) < cn[u] ? 1.0f : 0.0f;
-                        accA[u].x += msk * x[i].x; accA[u].y += msk * x[i].y; accA[u].z += msk * x[i].z; accA[u].w += msk * x[i].w;
+                        if ((k0 + 16 * i + kk) < cn[u] && (f[i] & 1)) {
+                            accA[u].x += x[i].x; accA[u].y += x[i].y; accA[u].z += x[i].z; accA[u].w += x[i].w;
+                        }
                     }
                 }
                 for (uint32_t k0 = 64; k0 < cn[u]; k0 += 256) {
                     float2 y[4];
+                    uint8_t f[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t kb = k0 + 64 * i + lane;
                         y[i] = base2[(size_t)(kb < cn[u] ? kb : 0) * (GRAD_STRIDE / 2) + 8];
+                        f[i] = a.rec_flag[of[u] + (kb < cn[u] ? kb : 0)];
                     }
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const float mb = (k0 + 64 * i + lane) < cn[u] ? 1.0f : 0.0f;
-                        accB[u].x += mb * y[i].x; accB[u].y += mb * y[i].y;
+                        if ((k0 + 64 * i + lane) < cn[u] && (f[i] & 2)) { accB[u].x += y[i].x; accB[u].y += y[i].y; }
                     }
                 }
             }
