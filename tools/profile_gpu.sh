@@ -9,12 +9,14 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+# kernel trace + stats of the SAME command the driver runs (default steps / warm-up; the CPU-baseline leg launches no kernels)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --workload $WL --no-cpu-baseline > $OUT/stats.log 2>&1
+grep '^{"metric"' $OUT/stats.log > $OUT/bench_under_rocprof.json
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -- $BENCH > $OUT/pmc_$name.log 2>&1
 done
-python $REPO/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python $REPO/tools/summarize_prof.py $OUT $OUT/traffic_$WL.json $WL > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -1,5 +1,8 @@
-"""Condenses rocprofv3 CSV output (kernel stats + PMC passes) into a small text table."""
-import csv, glob, os, sys, collections
+"""Condenses rocprofv3 CSV output (kernel stats + PMC passes) into a small text table.
+
+    summarize_prof.py <dir> [traffic.json workload]   # also writes the FETCH_SIZE/WRITE_SIZE table bench.py reads
+"""
+import csv, glob, json, os, sys, collections
 
 out = sys.argv[1]
 def short(n):
@@ -27,3 +30,23 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
     print(k)
     for c in sorted(agg[k]):
         print(f"    {c:28s} {agg[k][c] / max(cnt[k][c], 1):16.1f}")
+
+# HBM traffic table for bench.py's roofline.traffic (profiles/traffic_<workload>.json)
+if len(sys.argv) >= 4:
+    names = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_fwd_kernel": "preprocess_fwd",
+             "fold_records_kernel": "fold_records", "preprocess_bwd_kernel": "preprocess_bwd", "emit_kernel": "emit",
+             "tile_ranges_kernel": "tile_ranges"}
+    kern = {}
+    for k in agg:
+        key = names.get(k) or ("tile_sort" if k.startswith("radix_scatter_kernel<unsigned long") else None)
+        if key and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            kern[key] = {"FETCH_SIZE": round(agg[k]["FETCH_SIZE"] / max(cnt[k]["FETCH_SIZE"], 1), 1),
+                         "WRITE_SIZE": round(agg[k]["WRITE_SIZE"] / max(cnt[k]["WRITE_SIZE"], 1), 1)}
+    json.dump({"workload": sys.argv[3],
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, mean per dispatch, KiB "
+                         "(tools/profile_gpu.sh)",
+               "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE under-reports coalesced "
+                             "reads by ~2x (MI355X_MICROARCH.md; re-checked on kernels with known byte counts: "
+                             "radix_hist<u32> reads 6.0 MB -> FETCH 2.94 MB (x2.04), preprocess_fwd writes 170 MB -> "
+                             "WRITE_SIZE 170 MB (x1.00))",
+               "kernels": kern}, open(sys.argv[2], "w"), indent=1)
