@@ -1,4 +1,4 @@
-"""ctypes loader of the C-ABI library (include/g4s_rasterizer.h).
+"""ctypes loader of the C-ABI library (include/g4s_rasterizer.h, include/g4s_render_maps.h).
 
 There is deliberately NO fallback: if libg4s_hip.so is missing or fails to load, importing the
 operators raises.  The product path never routes through the CPU oracle or any torch emulation."""
@@ -42,6 +42,12 @@ SIGNATURES = {
     "g4s_profile_name": (ctypes.c_char_p, [c_i]),
     "g4s_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
     "g4s_profile_reset": (None, []),
+    # include/g4s_render_maps.h
+    "g4s_render_maps_workspace": (c_sz, []),
+    "g4s_render_maps_forward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz,
+                                      c_p]),
+    "g4s_render_maps_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                       c_p, c_sz, c_p]),
 }
 
 _lib = None

@@ -15,6 +15,9 @@
 using namespace g4s;
 
 extern "C" int g4s_knn_launch_internal(int P, const float* points, float* meanDists, char* workspace, hipStream_t s);
+extern "C" void g4s_maps_launch_internal(int fwd, int W, int H, float depth_ratio, const float* allmap, const float* wvt,
+                                         const float* fpt, float* cam, float* const* outs, const float* surf_depth_in,
+                                         const float* const* grads, float* g_allmap, hipStream_t s);
 
 namespace {
 
@@ -61,9 +64,10 @@ inline bool misaligned(const void* p, size_t a) { return p != nullptr && ((size_
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum ProfId { PF_PREPROCESS_FWD, PF_DEPTH_SORT, PF_COUNT_SCAN, PF_EMIT, PF_TILE_SORT, PF_TILE_RANGES, PF_BLEND_FWD,
-              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_COUNT };
+              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_COUNT };
 const char* const kProfNames[PF_COUNT] = {"preprocess_fwd", "depth_sort", "count_scan", "emit", "tile_sort",
-                                          "tile_ranges",    "blend_fwd",  "blend_bwd",  "preprocess_bwd"};
+                                          "tile_ranges",    "blend_fwd",  "blend_bwd",  "preprocess_bwd",
+                                          "maps_fwd",       "maps_bwd"};
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -427,5 +431,54 @@ extern "C" int g4s_knn_mean_dist(int P, const float* points, float* meanDists, c
     if (workspace_bytes < g4s_knn_workspace(P)) return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
     g4s_knn_launch_internal(P, points, meanDists, workspace, stream);
     CHECK_LAUNCH("knn");
+    return G4S_OK;
+}
+
+// ---- fused render() map post-processing (include/g4s_render_maps.h) -------------------------------
+#include "../../include/g4s_render_maps.h"
+
+extern "C" size_t g4s_render_maps_workspace(void) { return 512; }
+
+extern "C" int g4s_render_maps_forward(int width, int height, const float* allmap, const float* world_view_transform,
+                                       const float* full_proj_transform, float depth_ratio, float* rend_alpha,
+                                       float* rend_normal, float* rend_normal_cam, float* rend_depth, float* rend_dist,
+                                       float* surf_depth, float* surf_normal, float* surf_normal_cam, char* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "width, height must be positive");
+    if (!allmap || !world_view_transform || !full_proj_transform || !rend_alpha || !rend_normal || !rend_normal_cam ||
+        !rend_depth || !rend_dist || !surf_depth || !surf_normal || !surf_normal_cam)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (!workspace || workspace_bytes < g4s_render_maps_workspace()) return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    float* outs[8] = {rend_alpha, rend_normal, rend_normal_cam, rend_depth, rend_dist, surf_depth, surf_normal, surf_normal_cam};
+    { ProfScope ps(PF_MAPS_FWD, stream);
+      g4s_maps_launch_internal(1, width, height, depth_ratio, allmap, world_view_transform, full_proj_transform,
+                               (float*)align_ptr(workspace), outs, nullptr, nullptr, nullptr, stream); }
+    CHECK_LAUNCH("render_maps_forward");
+    return G4S_OK;
+}
+
+extern "C" int g4s_render_maps_backward(int width, int height, const float* allmap, const float* surf_depth,
+                                        const float* world_view_transform, const float* full_proj_transform,
+                                        float depth_ratio, const float* dL_rend_alpha, const float* dL_rend_normal,
+                                        const float* dL_rend_normal_cam, const float* dL_rend_depth,
+                                        const float* dL_rend_dist, const float* dL_surf_depth, const float* dL_surf_normal,
+                                        const float* dL_surf_normal_cam, float* dL_dallmap, char* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "width, height must be positive");
+    if (!allmap || !surf_depth || !world_view_transform || !full_proj_transform || !dL_dallmap)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (!workspace || workspace_bytes < g4s_render_maps_workspace()) return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    const float* grads[8] = {dL_rend_alpha, dL_rend_normal, dL_rend_normal_cam, dL_rend_depth, dL_rend_dist,
+                             dL_surf_depth, dL_surf_normal, dL_surf_normal_cam};
+    { ProfScope ps(PF_MAPS_BWD, stream);
+      g4s_maps_launch_internal(0, width, height, depth_ratio, allmap, world_view_transform, full_proj_transform,
+                               (float*)align_ptr(workspace), nullptr, surf_depth, grads, dL_dallmap, stream); }
+    CHECK_LAUNCH("render_maps_backward");
     return G4S_OK;
 }

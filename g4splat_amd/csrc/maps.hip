@@ -1,0 +1,291 @@
+// Fused map post-processing of render() (include/g4s_render_maps.h).
+//
+// Reference semantics: 2dgs/gaussian_renderer/__init__.py:117-164 and 2dgs/utils/point_utils.py:9-37
+// (about fifteen element-wise torch kernels + two 3x3 matmuls over [H,W,3] + a cross product).
+//
+// MI355X design: pure HBM streaming.  One thread per pixel, 64x4-pixel blocks (a wave reads 256
+// contiguous bytes of every plane); the 4-neighbour stencil of the depth-to-normal step re-reads
+// neighbouring pixels through L1/L2 instead of staging tiles (the planes are read once from HBM:
+// 28 B in + 64 B out per pixel forward).  The backward is the gather form of the stencil's adjoint
+// -- every pixel recomputes the normals of its four neighbours from the saved surf_depth -- so there
+// are no atomics and the result is bit-reproducible.  The camera algebra (two 4x4 / 3x3 inverses)
+// runs once per call in one thread, in double, into a 160-byte device scratch.
+#include "g4s_internal.h"
+#include "g4s_device.h"
+
+namespace g4s {
+
+// ---- camera algebra (point_utils.py:10-21) ------------------------------------------------------
+__device__ bool invert4(const double* m, double* inv) {
+    // adjugate / determinant of a row-major 4x4
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    if (det == 0.0) return false;
+    const double r = 1.0 / det;
+    for (int i = 0; i < 16; i++) inv[i] *= r;
+    return true;
+}
+
+// cam: [0..8] Rv = world_view_transform[:3,:3] (row-major), [9..17] Rd (rays_d = (x, y, 1) @ Rd),
+//      [18..20] rays_o.  A singular camera gives NaNs, as torch.inverse would raise.
+__global__ void maps_camera_kernel(const float* __restrict__ wvt, const float* __restrict__ fpt, int W, int H,
+                                   float* __restrict__ cam) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double Wm[16], Winv[16], FP[16];
+    for (int i = 0; i < 16; i++) { Wm[i] = wvt[i]; FP[i] = fpt[i]; }
+    const bool ok = invert4(Wm, Winv);  // c2w = (wvt^T)^-1 = Winv^T
+    // projection_matrix = c2w^T @ full_proj_transform = Winv @ FP
+    double M[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += Winv[4 * r + k] * FP[4 * k + c];
+            M[4 * r + c] = s;
+        }
+    // ndc2pix (4x3) = [[W/2,0,0,W/2],[0,H/2,0,H/2],[0,0,0,1]]^T ; intrins = (M @ ndc2pix)[:3,:3]^T
+    const double N[12] = {W / 2.0, 0, 0, 0, H / 2.0, 0, 0, 0, 0, W / 2.0, H / 2.0, 1.0};
+    double K[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += M[4 * r + k] * N[3 * k + c];
+            K[3 * c + r] = s;  // transposed
+        }
+    const double det = K[0] * (K[4] * K[8] - K[5] * K[7]) - K[1] * (K[3] * K[8] - K[5] * K[6]) + K[2] * (K[3] * K[7] - K[4] * K[6]);
+    const double rdet = 1.0 / det;
+    double Ki[9];
+    Ki[0] = (K[4] * K[8] - K[5] * K[7]) * rdet; Ki[1] = (K[2] * K[7] - K[1] * K[8]) * rdet; Ki[2] = (K[1] * K[5] - K[2] * K[4]) * rdet;
+    Ki[3] = (K[5] * K[6] - K[3] * K[8]) * rdet; Ki[4] = (K[0] * K[8] - K[2] * K[6]) * rdet; Ki[5] = (K[2] * K[3] - K[0] * K[5]) * rdet;
+    Ki[6] = (K[3] * K[7] - K[4] * K[6]) * rdet; Ki[7] = (K[1] * K[6] - K[0] * K[7]) * rdet; Ki[8] = (K[0] * K[4] - K[1] * K[3]) * rdet;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            cam[3 * r + c] = wvt[4 * r + c];
+            // rays_d = pix @ Ki^T @ c2w[:3,:3]^T = pix @ (Ki^T @ Winv[:3,:3])
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += Ki[3 * k + r] * Winv[4 * k + c];
+            cam[9 + 3 * r + c] = (float)(ok ? s : nan);
+        }
+    for (int c = 0; c < 3; c++) cam[18 + c] = (float)(ok ? Winv[12 + c] : nan);  // rays_o = c2w[:3,3]
+}
+
+struct MapsCam {
+    float Rv[9], Rd[9], o[3];
+};
+__device__ __forceinline__ MapsCam load_cam(const float* __restrict__ cam) {
+    MapsCam c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { c.Rv[i] = cam[i]; c.Rd[i] = cam[9 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) c.o[i] = cam[18 + i];
+    return c;
+}
+
+// torch.nan_to_num(x, 0, 0): nan -> 0, +inf -> 0, -inf -> lowest finite (neginf keeps its default)
+__device__ __forceinline__ float nan_to_num00(float v) {
+    if (v != v) return 0.0f;
+    if (v == __builtin_huge_valf()) return 0.0f;
+    if (v == -__builtin_huge_valf()) return -3.4028234663852886e38f;
+    return v;
+}
+__device__ __forceinline__ bool passes_grad(float v) { return v == v && fabsf(v) != __builtin_huge_valf(); }
+
+__device__ __forceinline__ float surf_depth_of(float D, float a, float med, float omr, float r, float* expected) {
+    const float e = nan_to_num00(D / a);
+    if (expected) *expected = e;
+    return e * omr + r * nan_to_num00(med);
+}
+
+__device__ __forceinline__ F3 ray_dir(const MapsCam& c, int x, int y) {
+    const float xf = (float)x, yf = (float)y;
+    return mk3(fmaf(xf, c.Rd[0], fmaf(yf, c.Rd[3], c.Rd[6])), fmaf(xf, c.Rd[1], fmaf(yf, c.Rd[4], c.Rd[7])),
+               fmaf(xf, c.Rd[2], fmaf(yf, c.Rd[5], c.Rd[8])));
+}
+__device__ __forceinline__ F3 back_project(const MapsCam& c, int x, int y, float depth) {
+    const F3 d = ray_dir(c, x, y);
+    return mk3(depth * d.x + c.o[0], depth * d.y + c.o[1], depth * d.z + c.o[2]);  // point_utils.py:23
+}
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+struct MapsArgs {
+    int W, H;
+    float r, omr;  // depth_ratio, 1 - depth_ratio
+    const float* allmap;
+    const float* cam;
+    // forward outputs
+    float *rend_alpha, *rend_normal, *rend_normal_cam, *rend_depth, *rend_dist, *surf_depth, *surf_normal, *surf_normal_cam;
+    // backward inputs / output
+    const float* surf_depth_in;
+    const float *g_alpha, *g_normal, *g_normal_cam, *g_depth, *g_dist, *g_surf_depth, *g_surf_normal, *g_surf_normal_cam;
+    float* g_allmap;
+};
+
+constexpr int MAPS_BX = 64, MAPS_BY = 4;
+
+__global__ void __launch_bounds__(MAPS_BX * MAPS_BY) maps_fwd_kernel(MapsArgs a) {
+    const int x = (int)(blockIdx.x * MAPS_BX + threadIdx.x % MAPS_BX), y = (int)(blockIdx.y * MAPS_BY + threadIdx.x / MAPS_BX);
+    if (x >= a.W || y >= a.H) return;
+    const MapsCam c = load_cam(a.cam);
+    const size_t N = (size_t)a.W * a.H, p = (size_t)a.W * y + x;
+    const float* m = a.allmap;
+    const float D = m[p], al = m[p + N], n0 = m[p + 2 * N], n1 = m[p + 3 * N], n2 = m[p + 4 * N], med = m[p + 5 * N];
+    a.rend_alpha[p] = al;
+    a.rend_dist[p] = m[p + 6 * N];
+    // (n @ Rv^T)[i] = sum_j n[j] Rv[i][j]   (__init__.py:123)
+    a.rend_normal[p] = n0 * c.Rv[0] + n1 * c.Rv[1] + n2 * c.Rv[2];
+    a.rend_normal[p + N] = n0 * c.Rv[3] + n1 * c.Rv[4] + n2 * c.Rv[5];
+    a.rend_normal[p + 2 * N] = n0 * c.Rv[6] + n1 * c.Rv[7] + n2 * c.Rv[8];
+    a.rend_normal_cam[p] = n0;
+    a.rend_normal_cam[p + N] = n1;
+    a.rend_normal_cam[p + 2 * N] = n2;
+    float e;
+    const float sd = surf_depth_of(D, al, med, a.omr, a.r, &e);
+    a.rend_depth[p] = e;
+    a.surf_depth[p] = sd;
+    F3 sn = mk3(0, 0, 0);
+    if (x >= 1 && x < a.W - 1 && y >= 1 && y < a.H - 1) {  // point_utils.py:33-36: 1-pixel border stays zero
+        auto P = [&](int xx, int yy) {
+            const size_t q = (size_t)a.W * yy + xx;
+            return back_project(c, xx, yy, surf_depth_of(m[q], m[q + N], m[q + 5 * N], a.omr, a.r, nullptr));
+        };
+        const F3 up = P(x, y - 1), dn = P(x, y + 1), lf = P(x - 1, y), rt = P(x + 1, y);
+        const F3 dx = mk3(dn.x - up.x, dn.y - up.y, dn.z - up.z);  // along rows (the reference calls it dx)
+        const F3 dy = mk3(rt.x - lf.x, rt.y - lf.y, rt.z - lf.z);
+        const F3 cr = cross3(dx, dy);
+        const float nrm = sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+        const float inv = 1.0f / fmaxf(nrm, 1e-12f);  // F.normalize eps
+        sn = mk3(cr.x * inv * al, cr.y * inv * al, cr.z * inv * al);  // * rend_alpha.detach()  (:146)
+    }
+    a.surf_normal[p] = sn.x;
+    a.surf_normal[p + N] = sn.y;
+    a.surf_normal[p + 2 * N] = sn.z;
+    // (sn @ Rv)[i] = sum_j sn[j] Rv[j][i]   (__init__.py:149)
+    a.surf_normal_cam[p] = sn.x * c.Rv[0] + sn.y * c.Rv[3] + sn.z * c.Rv[6];
+    a.surf_normal_cam[p + N] = sn.x * c.Rv[1] + sn.y * c.Rv[4] + sn.z * c.Rv[7];
+    a.surf_normal_cam[p + 2 * N] = sn.x * c.Rv[2] + sn.y * c.Rv[5] + sn.z * c.Rv[8];
+}
+
+// Adjoint of the normal of interior pixel (x, y) with respect to its two difference vectors:
+// returns dL/d(dx) in *gdx and dL/d(dy) in *gdy.
+__device__ __forceinline__ void normal_adjoint(const MapsArgs& a, const MapsCam& c, int x, int y, F3* gdx, F3* gdy) {
+    const size_t N = (size_t)a.W * a.H, q = (size_t)a.W * y + x;
+    const float* sdm = a.surf_depth_in;
+    const F3 up = back_project(c, x, y - 1, sdm[q - a.W]), dn = back_project(c, x, y + 1, sdm[q + a.W]);
+    const F3 lf = back_project(c, x - 1, y, sdm[q - 1]), rt = back_project(c, x + 1, y, sdm[q + 1]);
+    const F3 dx = mk3(dn.x - up.x, dn.y - up.y, dn.z - up.z), dy = mk3(rt.x - lf.x, rt.y - lf.y, rt.z - lf.z);
+    const F3 cr = cross3(dx, dy);
+    const float nrm = sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+    // total gradient of the world-space surf_normal: direct + through surf_normal_cam = sn @ Rv
+    F3 g = mk3(0, 0, 0);
+    if (a.g_surf_normal) g = mk3(a.g_surf_normal[q], a.g_surf_normal[q + N], a.g_surf_normal[q + 2 * N]);
+    if (a.g_surf_normal_cam) {
+        const float h0 = a.g_surf_normal_cam[q], h1 = a.g_surf_normal_cam[q + N], h2 = a.g_surf_normal_cam[q + 2 * N];
+        g.x += h0 * c.Rv[0] + h1 * c.Rv[1] + h2 * c.Rv[2];
+        g.y += h0 * c.Rv[3] + h1 * c.Rv[4] + h2 * c.Rv[5];
+        g.z += h0 * c.Rv[6] + h1 * c.Rv[7] + h2 * c.Rv[8];
+    }
+    const float al = a.allmap[q + N];  // detached weight
+    g = mk3(g.x * al, g.y * al, g.z * al);
+    F3 gc;
+    if (nrm > 1e-12f) {  // v / |v|: (g - u (u.g)) / |v|
+        const float inv = 1.0f / nrm;
+        const F3 u = mk3(cr.x * inv, cr.y * inv, cr.z * inv);
+        const float ug = u.x * g.x + u.y * g.y + u.z * g.z;
+        gc = mk3((g.x - u.x * ug) * inv, (g.y - u.y * ug) * inv, (g.z - u.z * ug) * inv);
+    } else {  // clamped denominator: v / eps
+        gc = mk3(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f);
+    }
+    *gdx = cross3(dy, gc);  // c = dx x dy  =>  dL/ddx = dy x gc, dL/ddy = gc x dx
+    *gdy = cross3(gc, dx);
+}
+
+__global__ void __launch_bounds__(MAPS_BX * MAPS_BY) maps_bwd_kernel(MapsArgs a) {
+    const int x = (int)(blockIdx.x * MAPS_BX + threadIdx.x % MAPS_BX), y = (int)(blockIdx.y * MAPS_BY + threadIdx.x / MAPS_BX);
+    if (x >= a.W || y >= a.H) return;
+    const MapsCam c = load_cam(a.cam);
+    const size_t N = (size_t)a.W * a.H, p = (size_t)a.W * y + x;
+    const float D = a.allmap[p], al = a.allmap[p + N], med = a.allmap[p + 5 * N];
+
+    // gradient reaching this pixel's back-projected point from the normals of its four neighbours
+    F3 gP = mk3(0, 0, 0);
+    if (a.g_surf_normal || a.g_surf_normal_cam) {
+        auto interior = [&](int xx, int yy) { return xx >= 1 && xx < a.W - 1 && yy >= 1 && yy < a.H - 1; };
+        F3 gdx, gdy;
+        if (interior(x, y - 1)) { normal_adjoint(a, c, x, y - 1, &gdx, &gdy); gP = mk3(gP.x + gdx.x, gP.y + gdx.y, gP.z + gdx.z); }
+        if (interior(x, y + 1)) { normal_adjoint(a, c, x, y + 1, &gdx, &gdy); gP = mk3(gP.x - gdx.x, gP.y - gdx.y, gP.z - gdx.z); }
+        if (interior(x - 1, y)) { normal_adjoint(a, c, x - 1, y, &gdx, &gdy); gP = mk3(gP.x + gdy.x, gP.y + gdy.y, gP.z + gdy.z); }
+        if (interior(x + 1, y)) { normal_adjoint(a, c, x + 1, y, &gdx, &gdy); gP = mk3(gP.x - gdy.x, gP.y - gdy.y, gP.z - gdy.z); }
+    }
+    const F3 d = ray_dir(c, x, y);
+    float g_sd = gP.x * d.x + gP.y * d.y + gP.z * d.z;
+    if (a.g_surf_depth) g_sd += a.g_surf_depth[p];
+    float g_e = g_sd * a.omr;
+    if (a.g_depth) g_e += a.g_depth[p];
+    // nan_to_num backward passes no gradient through replaced values; the division backward then is torch's
+    // grad / other and (-grad * self) / (other * other) -- which is NaN at alpha == 0 (0/0), exactly like the
+    // reference.  Such pixels have no contributor, so the rasterizer's backward never reads the value.
+    const float e = D / al;
+    const float g_em = passes_grad(e) ? g_e : 0.0f;
+    const float gD = g_em / al;
+    float gA = (-g_em * D) / (al * al);
+    if (a.g_alpha) gA += a.g_alpha[p];
+    const float gM = passes_grad(med) ? g_sd * a.r : 0.0f;
+    float gn0 = 0, gn1 = 0, gn2 = 0;
+    if (a.g_normal_cam) { gn0 = a.g_normal_cam[p]; gn1 = a.g_normal_cam[p + N]; gn2 = a.g_normal_cam[p + 2 * N]; }
+    if (a.g_normal) {
+        const float h0 = a.g_normal[p], h1 = a.g_normal[p + N], h2 = a.g_normal[p + 2 * N];
+        gn0 += h0 * c.Rv[0] + h1 * c.Rv[3] + h2 * c.Rv[6];
+        gn1 += h0 * c.Rv[1] + h1 * c.Rv[4] + h2 * c.Rv[7];
+        gn2 += h0 * c.Rv[2] + h1 * c.Rv[5] + h2 * c.Rv[8];
+    }
+    float* o = a.g_allmap;
+    o[p] = gD;
+    o[p + N] = gA;
+    o[p + 2 * N] = gn0;
+    o[p + 3 * N] = gn1;
+    o[p + 4 * N] = gn2;
+    o[p + 5 * N] = gM;
+    o[p + 6 * N] = a.g_dist ? a.g_dist[p] : 0.0f;
+}
+
+}  // namespace g4s
+
+using namespace g4s;
+
+extern "C" void g4s_maps_launch_internal(int fwd, int W, int H, float depth_ratio, const float* allmap, const float* wvt,
+                                         const float* fpt, float* cam, float* const* outs, const float* surf_depth_in,
+                                         const float* const* grads, float* g_allmap, hipStream_t s) {
+    hipLaunchKernelGGL(maps_camera_kernel, dim3(1), dim3(64), 0, s, wvt, fpt, W, H, cam);
+    MapsArgs a{};
+    a.W = W; a.H = H; a.r = depth_ratio; a.omr = (float)(1.0 - (double)depth_ratio);
+    a.allmap = allmap; a.cam = cam;
+    const dim3 grid((W + MAPS_BX - 1) / MAPS_BX, (H + MAPS_BY - 1) / MAPS_BY), block(MAPS_BX * MAPS_BY);
+    if (fwd) {
+        a.rend_alpha = outs[0]; a.rend_normal = outs[1]; a.rend_normal_cam = outs[2]; a.rend_depth = outs[3];
+        a.rend_dist = outs[4]; a.surf_depth = outs[5]; a.surf_normal = outs[6]; a.surf_normal_cam = outs[7];
+        hipLaunchKernelGGL(maps_fwd_kernel, grid, block, 0, s, a);
+    } else {
+        a.surf_depth_in = surf_depth_in;
+        a.g_alpha = grads[0]; a.g_normal = grads[1]; a.g_normal_cam = grads[2]; a.g_depth = grads[3]; a.g_dist = grads[4];
+        a.g_surf_depth = grads[5]; a.g_surf_normal = grads[6]; a.g_surf_normal_cam = grads[7];
+        a.g_allmap = g_allmap;
+        hipLaunchKernelGGL(maps_bwd_kernel, grid, block, 0, s, a);
+    }
+}

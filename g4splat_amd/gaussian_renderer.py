@@ -6,44 +6,22 @@ Same signature, same camera / model attributes read, same returned dict keys and
     rend_alpha, rend_normal, rend_normal_cam, rend_dist, surf_depth,
     surf_normal, surf_normal_cam, rend_depth                                (:155-164)
 The rasterizer call goes to the HIP library through the drop-in `GaussianRasterizer`; the map
-post-processing is plain torch for now.
+post-processing (:117-164 + utils/point_utils.py:9-37) is one fused HIP
+kernel each way (`render_maps`).
 """
 import math
 
 import torch
 
 from .diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from .render_maps import render_maps
 
 
-def depths_to_points(view, depthmap):
-    """2dgs/utils/point_utils.py:9-24: back-project a depth map to world-space points."""
-    dev, dt = depthmap.device, depthmap.dtype
-    c2w = (view.world_view_transform.T).inverse()
-    W, H = int(view.image_width), int(view.image_height)
-    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], dtype=dt, device=dev).T
-    projection_matrix = c2w.T @ view.full_proj_transform
-    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
-    gx, gy = torch.meshgrid(torch.arange(W, device=dev, dtype=dt), torch.arange(H, device=dev, dtype=dt), indexing="xy")
-    pix = torch.stack([gx, gy, torch.ones_like(gx)], dim=-1).reshape(-1, 3)
-    rays_d = pix @ intrins.inverse().T @ c2w[:3, :3].T
-    rays_o = c2w[:3, 3]
-    return depthmap.reshape(-1, 1) * rays_d + rays_o
-
-
-def depth_to_normal(view, depth):
-    """2dgs/utils/point_utils.py:26-37: normals from central differences of the back-projected depth."""
-    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
-    out = torch.zeros_like(points)
-    dx = points[2:, 1:-1] - points[:-2, 1:-1]
-    dy = points[1:-1, 2:] - points[1:-1, :-2]
-    out[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
-    return out
-
-
-def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rasterizer_cls=None):
-    """Render one view.  `rasterizer_cls` (default: the HIP GaussianRasterizer) exists only so that the
-    CPU test-suite can drive this function's post-processing with the oracle; the product path never
-    passes it."""
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rasterizer_cls=None,
+           maps_fn=None):
+    """Render one view.  `rasterizer_cls` / `maps_fn` (defaults: the HIP GaussianRasterizer and the HIP
+    `render_maps`) exist only so that the CPU test-suite can drive this function's host logic with the
+    oracle; the product path never passes them."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -83,18 +61,5 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}
 
-    render_alpha = allmap[1:2]
-    render_normal = allmap[2:5]
-    render_normal_cam = render_normal.clone()
-    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
-    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
-    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
-    render_dist = allmap[6:7]
-    surf_depth = render_depth_expected * (1 - pipe.depth_ratio) + pipe.depth_ratio * render_depth_median
-    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
-    surf_normal = surf_normal * render_alpha.detach()  # rend_normal is un-normalised: weight alike
-    surf_normal_cam = (surf_normal.clone().permute(1, 2, 0) @ viewpoint_camera.world_view_transform[:3, :3]).permute(2, 0, 1)
-    rets.update({"rend_alpha": render_alpha, "rend_normal": render_normal, "rend_normal_cam": render_normal_cam,
-                 "rend_dist": render_dist, "surf_depth": surf_depth, "surf_normal": surf_normal,
-                 "surf_normal_cam": surf_normal_cam, "rend_depth": render_depth_expected})
+    rets.update((maps_fn or render_maps)(allmap, viewpoint_camera, pipe.depth_ratio))
     return rets

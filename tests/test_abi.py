@@ -1,4 +1,4 @@
-"""The C-ABI library loads without a GPU and exports exactly what include/g4s_rasterizer.h declares;
+"""The C-ABI library loads without a GPU and exports exactly what include/*.h declare;
 the ctypes signature table of the Python front-end matches the header (no compute calls here)."""
 import os
 import re
@@ -7,11 +7,11 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "g4s_rasterizer.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("g4s_rasterizer.h", "g4s_render_maps.h")]
 
 
 def declared_functions():
-    src = open(HEADER).read()
+    src = "\n".join(open(h).read() for h in HEADERS)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"typedef\s+struct.*?\}\s*\w+\s*;", "", src, flags=re.S)
     src = re.sub(r"typedef[^;]*;", "", src)
@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
         assert hasattr(hip_lib, name)
     for name in exported:
         if name.startswith("g4s_") and not name.endswith("_internal"):
-            assert name in decls, f"{name} exported but not declared in include/g4s_rasterizer.h"
+            assert name in decls, f"{name} exported but not declared in include/*.h"
 
 
 def test_ctypes_table_matches_header(hip_lib):
@@ -51,6 +51,7 @@ def test_version_and_error_strings(hip_lib):
     assert hip_lib.g4s_last_error() == b""
     assert hip_lib.g4s_knn_workspace(1000) > 0
     assert hip_lib.g4s_rasterizer_backward_workspace(10, 100) >= 100 * 80
+    assert hip_lib.g4s_render_maps_workspace() >= 84
     # layout query is pure host code
     import ctypes
     L = _layout(hip_lib, 1000, 5000, 640, 480)

@@ -8,6 +8,7 @@ import torch
 from cpu_rasterizer import OracleRasterizer
 from test_render_cpu import KEYS, _camera, _model
 from g4splat_amd.gaussian_renderer import render
+from oracle.render_maps_ref import render_maps as maps_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +29,7 @@ def _loss(out):
 def test_render_matches_oracle_driven_render(hip_lib):
     cam, pipe = _camera(), SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False)
     ref_model, hip_model = _model(seed=2), _model(seed=2)
-    ref = render(cam, ref_model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer)
+    ref = render(cam, ref_model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
     _loss(ref).backward()
     dev = torch.device("cuda:0")
     for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):

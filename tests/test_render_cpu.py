@@ -1,5 +1,5 @@
 """render(): dict keys / shapes / post-processing semantics (2dgs/gaussian_renderer/__init__.py:108-166),
-driven on the CPU through the oracle-backed rasterizer stand-in."""
+driven on the CPU through the oracle-backed rasterizer and map stand-ins (the product's are HIP-only)."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -8,7 +8,8 @@ import torch
 from cpu_rasterizer import OracleRasterizer
 from g4splat_amd import synthetic
 from g4splat_amd.gaussian_model import GaussianModel
-from g4splat_amd.gaussian_renderer import depth_to_normal, render
+from g4splat_amd.gaussian_renderer import render
+from oracle.render_maps_ref import depth_to_normal, render_maps as maps_ref
 
 KEYS = {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_normal_cam",
         "rend_dist", "surf_depth", "surf_normal", "surf_normal_cam", "rend_depth"}
@@ -38,7 +39,7 @@ def _model(P=300, seed=0):
 def test_render_dict_and_gradients():
     cam, model = _camera(), _model()
     pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False, convert_SHs_python=False)
-    out = render(cam, model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer)
+    out = render(cam, model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
     assert set(out) == KEYS
     H, W = 56, 80
     assert out["render"].shape == (3, H, W) and out["rend_alpha"].shape == (1, H, W)
@@ -66,8 +67,8 @@ def test_python_cov3d_path_matches_kernel_path():
     cam, model = _camera(), _model(P=120, seed=3)
     model.get_covariance = lambda mod=1: _covariance(model, mod)
     bg = torch.zeros(3)
-    a = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False), bg, rasterizer_cls=OracleRasterizer)
-    b = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=True), bg, rasterizer_cls=OracleRasterizer)
+    a = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False), bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    b = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=True), bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
     assert torch.allclose(a["render"], b["render"], atol=2e-4)
     assert torch.allclose(a["rend_alpha"], b["rend_alpha"], atol=2e-4)
 
