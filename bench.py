@@ -110,23 +110,28 @@ def main():
     dL_dothers = torch.randn((7, H, W), device=device, generator=g)
 
     # one persistent flat fp32 bucket holds the parameter gradients of this rank's view (xyz, SH,
-    # opacity, scale, rotation = 58 floats per Gaussian at SH degree 3); the backward writes straight into views of
-    # it (`out=`), so the exchange is ONE RCCL all-reduce over xGMI plus the small densification side channel
-    # (per-view ||grad_means2D|| and visibility summed, radii max-reduced).  Persistent buffers also keep torch's
-    # caching allocator out of the timed region (no record_stream-deferred frees of 350 MB blocks).
-    grad_out = side = rmax = bucket = None
+    # opacity, scale, rotation = 58 floats per Gaussian at SH degree 3) plus the densification side channel (per-view
+    # ||grad_means2D||, visibility); the backward writes straight into views of it (`out=`).  The exchange is
+    # g4splat_amd.parallel.RowSparseAllReduce: MAX all-reduce of the radii (-> max_radii2D and the union
+    # visibility), then ONE RCCL SUM all-reduce over xGMI of the rows visible on some rank (the whole bucket when
+    # that is most of them).  Persistent buffers keep torch's caching allocator out of the timed region.
+    grad_out = side = rmax = reducer = None
     if dist is not None:
+        from g4splat_amd.parallel import RowSparseAllReduce
         M = int(dev["sh"].shape[1])
         shapes = [("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 2)),
-                  ("dL_drotations", (P, 4))]
+                  ("dL_drotations", (P, 4)), ("side", (P, 2))]
         offs, o = [], 0
         for _n, shp in shapes:
             offs.append(o)
             o += (int(np.prod(shp)) + 63) // 64 * 64  # 256-B aligned views
         bucket = torch.zeros(o, device=device)
-        grad_out = {n: bucket[b:b + int(np.prod(shp))].view(shp) for (n, shp), b in zip(shapes, offs)}
-        side = torch.zeros((P, 2), device=device)
+        views = {n: bucket[b:b + int(np.prod(shp))].view(shp) for (n, shp), b in zip(shapes, offs)}
+        side = views.pop("side")
+        grad_out = views
         rmax = torch.zeros((P,), dtype=torch.int32, device=device)
+        reducer = RowSparseAllReduce(bucket, [v.view(P, -1) for v in grad_out.values()] + [side])
+    exchanged_rows = []
 
     def step(i):
         cam = dcams[(rank + i * world) % len(dcams)]
@@ -143,10 +148,9 @@ def main():
             torch.linalg.vector_norm(gm2[:, :2], dim=1, out=side[:, 0])
             side[:, 1] = radii > 0
             rmax.copy_(radii)
-            works = [dist.all_reduce(bucket, async_op=True), dist.all_reduce(side, async_op=True),
-                     dist.all_reduce(rmax, op=dist.ReduceOp.MAX, async_op=True)]
-            for w_ in works:
-                w_.wait()
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+            reducer.reduce(rmax > 0)
+            exchanged_rows.append(reducer.last_rows)
         return R, radii
 
     # warm-up (also measures V and R per view outside the timed region)
@@ -243,7 +247,9 @@ def main():
                                f"{len(dcams)} views, 1 view/GPU/step", "P": P, "width": W, "height": H,
                    "sh_degree": D, "visible_per_view": round(units / args.steps / world),
                    "instances_per_view": round(inst / args.steps / world),
-                   "parallelism": f"view-dp{world}" + ("+rccl-allreduce" if world > 1 else "")},
+                   "parallelism": f"view-dp{world}" + ("+rccl-allreduce" if world > 1 else ""),
+                   "exchanged_rows_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows
+                                               else None)},
         "gaussians_total_per_s": P * args.steps * world / elapsed,
         "instances_per_s": inst / elapsed,
         "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},

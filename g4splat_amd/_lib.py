@@ -37,6 +37,7 @@ SIGNATURES = {
     "g4s_knn_workspace": (c_sz, [c_i]),
     "g4s_knn_mean_dist": (c_i, [c_i, c_p, c_p, c_p, c_sz, c_p]),
     "g4s_rasterizer_layout": (c_i, [c_i, c_i, c_i, c_i, ctypes.POINTER(G4sLayout)]),
+    "g4s_pack_rows": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "g4s_profile_enable": (None, [c_i]),
     "g4s_profile_kernels": (c_i, []),
     "g4s_profile_name": (ctypes.c_char_p, [c_i]),

@@ -434,6 +434,24 @@ extern "C" int g4s_knn_mean_dist(int P, const float* points, float* meanDists, c
     return G4S_OK;
 }
 
+// ---- packed rows for the visible-rows gradient exchange ------------------------------------------
+extern "C" void g4s_pack_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, const long long* idx, int n,
+                                              float* packed, int unpack, hipStream_t s);
+
+extern "C" int g4s_pack_rows(int nseg, float* const* segments, const int* widths, const long long* row_index, int n,
+                             float* packed, int unpack, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (nseg < 1 || nseg > 8 || n < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "1..8 segments, n >= 0");
+    if (!segments || !widths || (n > 0 && (!row_index || !packed))) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
+    for (int i = 0; i < nseg; i++)
+        if (!segments[i] || widths[i] <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: NULL pointer or width <= 0", i);
+    g4s_pack_rows_launch_internal(nseg, segments, widths, row_index, n, packed, unpack, stream);
+    CHECK_LAUNCH("pack_rows");
+    return G4S_OK;
+}
+
 // ---- fused render() map post-processing (include/g4s_render_maps.h) -------------------------------
 #include "../../include/g4s_render_maps.h"
 

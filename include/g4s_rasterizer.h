@@ -157,6 +157,16 @@ typedef struct g4s_layout {
 
 int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
 
+/*
+ * Row packing for the multi-GPU gradient exchange (new functionality; no reference
+ * counterpart): gathers the rows `row_index[0..n)` of up to 8 row-major float segments
+ * (segment s = [P, widths[s]]) into one contiguous buffer, segment after segment
+ * (packed = [n*widths[0] | n*widths[1] | ...]), or scatters such a buffer back (`unpack` != 0).
+ * `segments` / `widths` are HOST arrays of device pointers / ints; `row_index` is a device int64 array.
+ */
+int g4s_pack_rows(int nseg, float* const* segments, const int* widths, const long long* row_index, int n,
+                  float* packed, int unpack, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py
  * for the roofline figure; off by default, process-wide).  Kernel groups 0..g4s_profile_kernels()-1
  * are named by g4s_profile_name().  g4s_profile_read() synchronises on the recorded events and

@@ -62,7 +62,7 @@ def _step(model, views, vp):
         vp.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, compact_below):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,13 +72,14 @@ def _worker(rank, world, port, q):
     model = _model(seed=rank)  # deliberately different replicas: the broadcast must fix that
     broadcast_parameters(model.parameters(), src=0)
     model.training_setup()
-    vp = ViewParallel(model.parameters())
+    vp = ViewParallel(model.parameters(), compact_below=compact_below)
     views = _views(4)
     mine = shard_views(views, rank, world)
     assert len(mine) == 2
     _step(model, mine, vp)
     stats = vp.all_reduce()
     flat = vp.bucket.flat.clone()
+    assert vp._reducer.last_rows == (150 if compact_below == 0.0 else int((stats["max_radii"] > 0).sum()))
     model.optimizer.step()
     q.put((rank, flat.numpy(), stats["grad_norm_sum"].numpy(), stats["vis_count"].numpy(), stats["max_radii"].numpy(),
            torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()))
@@ -86,12 +87,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_view_parallel_matches_single_process():
+@pytest.mark.parametrize("compact_below", [0.0, 1.1])  # dense exchange / visible-rows-only exchange
+def test_view_parallel_matches_single_process(compact_below):
     _setup_paths()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if compact_below else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact_below)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -133,3 +135,50 @@ def test_bucket_views_survive_zero_grad():
     b.zero()
     (ps[0].sum()).backward()
     assert b.flat.tolist() == [1.0] * 12 + [0.0] * 4
+
+
+def _sparse_worker(rank, world, port, q):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from g4splat_amd.parallel import RowSparseAllReduce
+    P = 1000
+    out = []
+    for frac in (0.0, 0.05, 0.5, 1.0):
+        g = torch.Generator().manual_seed(17)
+        union = torch.rand(P, generator=g) < frac  # same mask on every rank
+        mine = union & (torch.rand(P, generator=torch.Generator().manual_seed(100 + rank)) < 0.7)
+        flat = torch.zeros(P * 7)
+        rows = [flat[:3 * P].view(P, 3), flat[3 * P:].view(P, 4)]
+        vals = torch.randn(P, 7, generator=torch.Generator().manual_seed(200 + rank))
+        rows[0][mine] = vals[mine, :3]
+        rows[1][mine] = vals[mine, 3:]
+        dense = flat.clone()
+        dist.all_reduce(dense)
+        red = RowSparseAllReduce(flat, rows, compact_below=0.7)
+        red.reduce(union)
+        out.append((frac, bool(torch.equal(flat, dense)), red.last_rows, int(union.sum())))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sparse_all_reduce_equals_dense():
+    """Packed visible-rows exchange == dense all-reduce bit for bit (same two addends per row), for empty, small,
+    medium and full unions (the last one takes the dense path)."""
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        for frac, same, rows, n in res[r]:
+            assert same, (r, frac)
+            assert rows == (1000 if n > 700 else n), (frac, rows, n)

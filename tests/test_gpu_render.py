@@ -141,3 +141,31 @@ def test_metric_size_properties(hip_lib):
         scale = float(lin.abs().max())
         assert float((xy - lin).abs().max()) <= 2e-4 * scale + 1e-9, n
         assert not x[invisible].any(), n
+
+
+def test_pack_rows_roundtrip(hip_lib):
+    """g4s_pack_rows (visible-rows gradient exchange): pack == torch index_select per segment, unpack restores."""
+    import ctypes
+    P, widths = 5000, [3, 48, 1, 2, 4, 2]
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    segs = [torch.randn((P, w), device="cuda:0", generator=g) for w in widths]
+    idx = (torch.rand(P, device="cuda:0", generator=g) < 0.3).nonzero(as_tuple=True)[0]
+    n = int(idx.numel())
+    packed = torch.full((n * sum(widths),), float("nan"), device="cuda:0")
+    ptrs = (ctypes.c_void_p * len(segs))(*[s.data_ptr() for s in segs])
+    wid = (ctypes.c_int * len(segs))(*widths)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(packed.data_ptr()), 0, stream) == 0
+    want = torch.cat([s.index_select(0, idx).reshape(-1) for s in segs])
+    assert torch.equal(packed, want)
+    before = [s.clone() for s in segs]
+    packed *= 2.0
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(packed.data_ptr()), 1, stream) == 0
+    torch.cuda.synchronize()
+    keep = torch.ones(P, dtype=torch.bool, device="cuda:0")
+    keep[idx] = False
+    for s, b in zip(segs, before):
+        assert torch.equal(s[idx], 2.0 * b[idx]) and torch.equal(s[keep], b[keep])
+    assert hip_lib.g4s_pack_rows(9, ptrs, wid, None, 0, None, 0, stream) < 0
