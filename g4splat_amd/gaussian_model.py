@@ -1,7 +1,8 @@
 """Minimal GaussianModel-compatible parameter container: exactly the attributes `render()` and the
 training loop read (2dgs/scene/gaussian_model.py:157-266) -- getters with the reference's activations,
 `create_from_pcd` (distCUDA2 scale init), `create_from_parameters`, Adam groups with the reference's
-names / eps, and the densification statistics.  Densify / prune / PLY I/O are SURVEY.md 8(f) f3-f4."""
+names / eps, the densification statistics, and the reference's PLY format (save_ply / load_ply via
+ply_io.py).  Densify / prune are SURVEY.md 8(f) f3."""
 import torch
 from torch import nn
 
@@ -107,3 +108,25 @@ class GaussianModel:
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1,
                                                              keepdim=True)
         self.denom[update_filter] += 1
+
+    # ---- on-disk format (gaussian_model.py:293-315, 441-493) ----------------------------------
+    def save_ply(self, path):
+        from .ply_io import write_gaussian_ply
+        c = lambda t: t.detach().cpu().numpy()
+        write_gaussian_ply(path, c(self._xyz), c(self._features_dc), c(self._features_rest), c(self._opacity),
+                           c(self._scaling), c(self._rotation),
+                           c(self.mip_filter) if self.use_mip_filter and self.mip_filter is not None else None)
+
+    def load_ply(self, path, device=None):
+        """Loads a scene written by the reference (or by save_ply).  `device` defaults to "cuda" like the
+        reference (:484-491)."""
+        from .ply_io import read_gaussian_ply
+        d = read_gaussian_ply(path, self.max_sh_degree)
+        dev = torch.device(device if device is not None else "cuda")
+        par = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float, device=dev).requires_grad_(True))
+        self._xyz, self._features_dc, self._features_rest = par(d["xyz"]), par(d["features_dc"]), par(d["features_rest"])
+        self._opacity, self._scaling, self._rotation = par(d["opacity"]), par(d["scaling"]), par(d["rotation"])
+        self.use_mip_filter = d["mip_filter"] is not None
+        self.mip_filter = torch.tensor(d["mip_filter"], dtype=torch.float, device=dev) if self.use_mip_filter else None
+        self.max_radii2D = torch.zeros(self._xyz.shape[0], device=dev)
+        self.active_sh_degree = self.max_sh_degree
