@@ -64,10 +64,10 @@ inline bool misaligned(const void* p, size_t a) { return p != nullptr && ((size_
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum ProfId { PF_PREPROCESS_FWD, PF_DEPTH_SORT, PF_COUNT_SCAN, PF_EMIT, PF_TILE_SORT, PF_TILE_RANGES, PF_BLEND_FWD,
-              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_COUNT };
+              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_PHOTO_LOSS, PF_COUNT };
 const char* const kProfNames[PF_COUNT] = {"preprocess_fwd", "depth_sort", "count_scan", "emit", "tile_sort",
                                           "tile_ranges",    "blend_fwd",  "blend_bwd",  "preprocess_bwd",
-                                          "maps_fwd",       "maps_bwd"};
+                                          "maps_fwd",       "maps_bwd",   "photometric_loss"};
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -431,6 +431,26 @@ extern "C" int g4s_knn_mean_dist(int P, const float* points, float* meanDists, c
     if (workspace_bytes < g4s_knn_workspace(P)) return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
     g4s_knn_launch_internal(P, points, meanDists, workspace, stream);
     CHECK_LAUNCH("knn");
+    return G4S_OK;
+}
+
+// ---- fused photometric loss (include/g4s_losses.h) ------------------------------------------------
+#include "../../include/g4s_losses.h"
+extern "C" void g4s_photometric_launch_internal(int W, int H, const float* image, const float* gt, float lambda, float* out3,
+                                                float* dL_dimage, char* workspace, hipStream_t s);
+
+extern "C" int g4s_photometric_loss(int width, int height, const float* image, const float* gt, float lambda_dssim,
+                                    float* out3, float* dL_dimage, char* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "width, height must be positive");
+    if (!image || !gt || !out3) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (!workspace || workspace_bytes < g4s_photometric_workspace(width, height))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    { ProfScope ps(PF_PHOTO_LOSS, stream);
+      g4s_photometric_launch_internal(width, height, image, gt, lambda_dssim, out3, dL_dimage, workspace, stream); }
+    CHECK_LAUNCH("photometric_loss");
     return G4S_OK;
 }
 

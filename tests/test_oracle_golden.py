@@ -118,3 +118,19 @@ def test_loss_helpers_match_reference():
     np.testing.assert_allclose(metrics.l1_loss(a, b).numpy(), d["l1"], rtol=1e-6)
     np.testing.assert_allclose(metrics.ssim(a, b).numpy(), d["ssim"], rtol=1e-5)
     np.testing.assert_allclose(metrics.psnr(a[None], b[None]).numpy(), d["psnr"], rtol=1e-6)
+
+
+def test_photometric_loss_restatement_matches_the_reference():
+    """oracle/losses_ref.py against values AND gradients produced by the reference's own loss_utils.py
+    (tests/golden/make_golden_losses.py imports it): this part of the oracle is pinned."""
+    import torch
+    from oracle import losses_ref
+    g = np.load(os.path.join(G, "photometric.npz"))
+    for name in ("ragged", "tile", "tiny", "zeros"):
+        x = torch.tensor(g[f"{name}_image"], requires_grad=True)
+        loss, l1, ss = losses_ref.photometric_loss(x, torch.tensor(g[f"{name}_gt"]), float(g[f"{name}_lambda"]))
+        loss.backward()
+        assert abs(float(l1) - float(g[f"{name}_l1"])) <= 1e-7
+        assert abs(float(ss) - float(g[f"{name}_ssim"])) <= 1e-6
+        assert abs(float(loss) - float(g[f"{name}_loss"])) <= 1e-6
+        np.testing.assert_allclose(x.grad.numpy(), g[f"{name}_grad"], rtol=1e-5, atol=1e-9)
