@@ -83,6 +83,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # bring-up aids (never set by the driver): G4S_BENCH_BACKEND=gloo + G4S_BENCH_ONE_DEVICE=1 run several ranks on
+    # ONE GPU to exercise the N > 1 control flow where only a single-GPU box is available (RCCL refuses two ranks
+    # on one device); the numbers of such a run mean nothing.
+    backend = os.environ.get("G4S_BENCH_BACKEND", "nccl")
+    if os.environ.get("G4S_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
@@ -94,7 +100,10 @@ def main():
     if world > 1 or os.environ.get("G4S_FORCE_DIST"):  # G4S_FORCE_DIST: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from g4splat_amd import _lib, build
     build.build()
@@ -247,7 +256,8 @@ def main():
                                f"{len(dcams)} views, 1 view/GPU/step", "P": P, "width": W, "height": H,
                    "sh_degree": D, "visible_per_view": round(units / args.steps / world),
                    "instances_per_view": round(inst / args.steps / world),
-                   "parallelism": f"view-dp{world}" + ("+rccl-allreduce" if world > 1 else ""),
+                   "parallelism": f"view-dp{world}" + ((("+rccl" if backend == "nccl" else "+" + backend) +
+                                                                   "-visible-rows-allreduce") if world > 1 else ""),
                    "exchanged_rows_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows
                                                else None)},
         "gaussians_total_per_s": P * args.steps * world / elapsed,
