@@ -9,15 +9,17 @@
 //   * pixels are grouped in wave64-sized 8x8 quadrants.  Before any per-pixel arithmetic a
 //     quadrant is tested against the splat's alpha-cutoff box (record quad 5) with wave-uniform
 //     compares, and every expensive stage sits behind a wave-uniform __any();
-//   * forward: 4 waves per tile, one quadrant each; a quadrant stops as soon as its 64 pixels are
-//     saturated;
+//   * forward: 4 waves per tile, one quadrant each; a saturated pixel carries Tt = 0, a quadrant stops as
+//     soon as its 64 pixels are saturated; per instance the forward records which quadrants blended it
+//     (qhit, one byte);
 //   * backward: no float atomics anywhere.  ONE wave owns a whole tile, every lane owns four pixels
-//     (the same position in each quadrant): the sum over the tile's 256 pixels is 3 in-register
-//     adds plus one wave reduction built from gfx950's v_permlane32_swap / v_permlane16_swap
-//     (four values per 10 instructions), written as ONE 80-byte record per (tile, Gaussian)
-//     instance at a slot reserved for that Gaussian (inst_off + k).  The per-Gaussian kernel
-//     (preprocess.hip, K8) folds a Gaussian's contiguous records in a fixed order
-//     => bit-reproducible gradients, no workgroup barriers in the hot loop.
+//     (the same position in each quadrant); qhit is an exact work mask, so entries and quadrants without
+//     contribution are never touched.  The sum over the tile's 256 pixels is 3 in-register adds plus one
+//     wave reduction built from gfx950's v_permlane32_swap / v_permlane16_swap (sixteen terms at once,
+//     g4s_device.h), written as ONE 80-byte record per (tile, Gaussian) instance at a slot reserved for that
+//     Gaussian (inst_off + k) and flagged valid in a byte array.  The per-Gaussian kernel (preprocess.hip,
+//     K8) folds a Gaussian's contiguous records in a fixed order => bit-reproducible gradients, no
+//     workgroup barriers in the hot loop.
 #include "g4s_internal.h"
 #include "g4s_device.h"
 
@@ -239,8 +241,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 
     // list positions >= the tile's max last_contributor cannot contribute anywhere
     const int n_live = (int)wave_max_u32(max_last);
-    // (records of instances that receive no contribution are never written: the caller clears the
-    //  record buffer with one streaming memset instead of ~Rb scattered 80-byte zero stores)
+    // (records of instances that receive no contribution are never written; rec_flag tells the fold which are)
 
     // batches from the back of the live range; lane t stages list position hi-1-t
     for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
