@@ -301,3 +301,33 @@ def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys):
         assert l2 <= GRAD_RTOL, (name, l2)
     with capsys.disabled():
         print("gradient rows beyond 1e-3 / relative L2 error:", rep)
+
+
+@pytest.mark.parametrize("block", range(20))
+def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
+    """Two hundred seeded random configurations (image sizes that are not multiples of the tile, 1-pixel-high images,
+    huge and tiny splats, translucent and opaque, every SH degree, scale modifiers, backgrounds, fields of view)
+    against the oracle: outputs, radii, instance counts, culled tile lists, gradients."""
+    for case in range(10):
+        seed = 1000 + 10 * block + case
+        rng = np.random.default_rng(seed)
+        W = int(rng.choice([1, 7, 16, 33, 100, 161, 250]))
+        H = int(rng.choice([1, 5, 16, 47, 96, 130]))
+        P = int(rng.choice([1, 2, 17, 300, 2000, 6000]))
+        D = int(rng.integers(0, 4))
+        inp = scene_inputs(P=P, W=W, H=H, seed=seed, D=D, bg=tuple(rng.uniform(0, 1, 3)),
+                           scale_mul=float(rng.choice([0.05, 0.5, 1.0, 4.0, 20.0])),
+                           opacity_max=float(rng.choice([0.02, 0.3, 1.0])),
+                           scale_modifier=float(rng.choice([1.0, 1.0, 0.7, 1.6])), fov_deg=float(rng.uniform(25, 110)))
+        g = cotangents(H, W, seed=seed)
+        o = run_oracle(oracle_mod, inp, g)
+        h = run_hip(inp, g)
+        tag = f"seed {seed}: P={P} {W}x{H} D={D}"
+        assert h["R"] == o["R"], tag
+        np.testing.assert_array_equal(h["radii"], o["radii"], err_msg=tag)
+        assert np.abs(h["color"] - o["color"]).max() <= OUT_ATOL, tag
+        assert np.abs(h["others"] - o["others"]).max() <= OUT_ATOL, tag
+        if o["R"] > 0:
+            check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
+        for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
+            assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, (tag, name)
