@@ -64,10 +64,11 @@ inline bool misaligned(const void* p, size_t a) { return p != nullptr && ((size_
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum ProfId { PF_PREPROCESS_FWD, PF_DEPTH_SORT, PF_COUNT_SCAN, PF_EMIT, PF_TILE_SORT, PF_TILE_RANGES, PF_BLEND_FWD,
-              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_PHOTO_LOSS, PF_COUNT };
+              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_PHOTO_LOSS, PF_ADAM, PF_COUNT };
 const char* const kProfNames[PF_COUNT] = {"preprocess_fwd", "depth_sort", "count_scan", "emit", "tile_sort",
                                           "tile_ranges",    "blend_fwd",  "blend_bwd",  "preprocess_bwd",
-                                          "maps_fwd",       "maps_bwd",   "photometric_loss"};
+                                          "maps_fwd",       "maps_bwd",   "photometric_loss",
+                                          "adam"};
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -451,6 +452,31 @@ extern "C" int g4s_photometric_loss(int width, int height, const float* image, c
     { ProfScope ps(PF_PHOTO_LOSS, stream);
       g4s_photometric_launch_internal(width, height, image, gt, lambda_dssim, out3, dL_dimage, workspace, stream); }
     CHECK_LAUNCH("photometric_loss");
+    return G4S_OK;
+}
+
+// ---- fused Adam (include/g4s_optim.h) ---------------------------------------------------------------
+#include "../../include/g4s_optim.h"
+extern "C" void g4s_adam_launch_internal(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
+                                         float* const* exp_avg_sq, const long long* numel, const double* lr, const int* step,
+                                         double beta1, double beta2, double eps, hipStream_t s);
+
+extern "C" int g4s_adam_step(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
+                             float* const* exp_avg_sq, const long long* numel, const double* lr, const int* step, double beta1,
+                             double beta2, double eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (nseg < 1 || nseg > 8) return fail(G4S_ERR_INVALID_ARGUMENT, "1..8 segments");
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr || !step) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL array");
+    for (int i = 0; i < nseg; i++) {
+        if (numel[i] < 0 || step[i] < 1) return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: numel < 0 or step < 1", i);
+        if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))
+            return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: NULL pointer", i);
+    }
+    { ProfScope ps(PF_ADAM, stream);
+      g4s_adam_launch_internal(nseg, params, grads, exp_avg, exp_avg_sq, numel, lr, step, beta1, beta2, eps, stream); }
+    CHECK_LAUNCH("adam_step");
     return G4S_OK;
 }
 

@@ -191,3 +191,80 @@ extern "C" void g4s_photometric_launch_internal(int W, int H, const float* image
     hipLaunchKernelGGL(photo_reduce_kernel, dim3(1), dim3(256), 0, s, a);
     if (dL_dimage) hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, s, a);
 }
+
+// ---- fused Adam over up to eight parameter segments (include/g4s_optim.h) ------------------------------
+namespace g4s {
+struct AdamSegs {
+    float* p[8];
+    const float* g[8];
+    float* m[8];
+    float* v[8];
+    long long n[8];        // elements
+    long long first[9];    // first float4-block of each segment in the launch's block space (prefix sums)
+    float step_size[8];    // lr / (1 - beta1^t)
+    float inv_sqrt_bc2[8]; // 1 / sqrt(1 - beta2^t)
+    int nseg;
+    float w1, w2, beta2, eps;  // 1 - beta1, 1 - beta2 (formed in double on the host), beta2, eps
+};
+
+// One thread per 4 consecutive floats (16-byte accesses when the segment base is 16-byte aligned, which torch
+// allocations are; the tail and misaligned bases fall back to scalar accesses).
+__global__ void __launch_bounds__(256) adam_kernel(AdamSegs a) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // float4-block index over all segments
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) s += (i < a.nseg && q >= a.first[i]) ? 1 : 0;
+    const long long e0 = (q - a.first[s]) * 4;
+    if (q >= a.first[a.nseg] || e0 >= a.n[s]) return;
+    float* p = a.p[s] + e0;
+    const float* g = a.g[s] + e0;
+    float* m = a.m[s] + e0;
+    float* v = a.v[s] + e0;
+    const float w1 = a.w1, w2 = a.w2, ss = a.step_size[s], ib = a.inv_sqrt_bc2[s];
+    const bool vec = e0 + 4 <= a.n[s] && (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
+    float pv[4], gv[4], mv[4], vv[4];
+    const int cnt = vec ? 4 : (int)((a.n[s] - e0) < 4 ? (a.n[s] - e0) : 4);
+    if (vec) {
+        *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(p);
+        *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(g);
+        *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(m);
+        *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(v);
+    } else {
+        for (int i = 0; i < cnt; i++) { pv[i] = p[i]; gv[i] = g[i]; mv[i] = m[i]; vv[i] = v[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i >= cnt) break;
+        mv[i] = mv[i] + w1 * (gv[i] - mv[i]);              // exp_avg.lerp_(grad, 1 - beta1)
+        vv[i] = a.beta2 * vv[i] + w2 * gv[i] * gv[i];      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vv[i]) * ib + a.eps;     // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+        pv[i] = pv[i] - ss * (mv[i] / denom);              // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    if (vec) {
+        *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(pv);
+        *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(mv);
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(vv);
+    } else {
+        for (int i = 0; i < cnt; i++) { p[i] = pv[i]; m[i] = mv[i]; v[i] = vv[i]; }
+    }
+}
+}  // namespace g4s
+
+extern "C" void g4s_adam_launch_internal(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
+                                         float* const* exp_avg_sq, const long long* numel, const double* lr, const int* step,
+                                         double beta1, double beta2, double eps, hipStream_t s) {
+    AdamSegs a{};
+    a.nseg = nseg; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2); a.beta2 = (float)beta2; a.eps = (float)eps;
+    long long blocks4 = 0;
+    for (int i = 0; i < nseg; i++) {
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i]; a.n[i] = numel[i];
+        a.first[i] = blocks4;
+        blocks4 += (numel[i] + 3) / 4;
+        const double bc1 = 1.0 - pow(beta1, (double)step[i]), bc2 = 1.0 - pow(beta2, (double)step[i]);
+        a.step_size[i] = (float)(lr[i] / bc1);
+        a.inv_sqrt_bc2[i] = (float)(1.0 / sqrt(bc2));
+    }
+    for (int i = nseg; i <= 8; i++) a.first[i] = blocks4;
+    if (blocks4 == 0) return;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, s, a);
+}

@@ -89,7 +89,9 @@ class GaussianModel:
 
     # ---- optimisation ------------------------------------------------------------------------------
     def training_setup(self, position_lr=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
-                       rotation_lr=0.001):
+                       rotation_lr=0.001, fused=None):
+        """gaussian_model.py:248-266.  `fused` (default: on for HIP tensors): one-kernel Adam (optim.FusedAdam)
+        instead of torch.optim.Adam's foreach passes; same groups, names, lr, eps and state layout."""
         n, dev = self._xyz.shape[0], self._xyz.device
         self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
         self.denom = torch.zeros((n, 1), device=dev)
@@ -101,7 +103,13 @@ class GaussianModel:
             {"params": [self._scaling], "lr": scaling_lr, "name": "scaling"},
             {"params": [self._rotation], "lr": rotation_lr, "name": "rotation"},
         ]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        if fused is None:
+            fused = self._xyz.is_cuda
+        if fused:
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         """gaussian_model.py:649-651: accumulate the per-view norm of the screen-space gradient."""

@@ -7,7 +7,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = [os.path.join(ROOT, "include", h) for h in ("g4s_rasterizer.h", "g4s_render_maps.h", "g4s_losses.h")]
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("g4s_rasterizer.h", "g4s_render_maps.h", "g4s_losses.h", "g4s_optim.h")]
 
 
 def declared_functions():
