@@ -2,9 +2,12 @@
 training loop read (2dgs/scene/gaussian_model.py:157-266) -- getters with the reference's activations,
 `create_from_pcd` (distCUDA2 scale init), `create_from_parameters`, Adam groups with the reference's
 names / eps, the densification statistics, and the reference's PLY format (save_ply / load_ply via
-ply_io.py).  Densify / prune are SURVEY.md 8(f) f3."""
+ply_io.py); adaptive density control (prune / clone / split / reset_opacity / mip filter) comes from
+densify.py."""
 import torch
 from torch import nn
+
+from .densify import DensifyMixin
 
 C0 = 0.28209479177387814
 
@@ -13,7 +16,7 @@ def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
 
-class GaussianModel:
+class GaussianModel(DensifyMixin):
     def __init__(self, sh_degree=3, use_mip_filter=False):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree

@@ -1,0 +1,123 @@
+"""Adaptive density control (g4splat_amd/densify.py) against the rules of 2dgs/scene/gaussian_model.py:436-651,
+on CPU tensors with torch.optim.Adam (the same code runs on HIP tensors with FusedAdam)."""
+import numpy as np
+import torch
+
+from g4splat_amd.densify import build_rotation
+from g4splat_amd.gaussian_model import GaussianModel
+
+
+def _model(P=40, seed=0):
+    rng = np.random.default_rng(seed)
+    m = GaussianModel(sh_degree=2)
+    scales = np.where(np.arange(P)[:, None] % 2 == 0, 0.004, 0.3) * np.ones((P, 2))  # even rows small, odd rows large
+    m.create_from_parameters(torch.tensor(rng.normal(size=(P, 3)).astype(np.float32)),
+                             torch.tensor(scales.astype(np.float32)),
+                             torch.tensor(rng.normal(size=(P, 4)).astype(np.float32)),
+                             torch.tensor(rng.uniform(0, 1, (P, 3)).astype(np.float32)))
+    with torch.no_grad():
+        m._opacity[:] = 2.0  # sigmoid = 0.88
+    m.training_setup(fused=False)
+    # one optimiser step so that every group has moments
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    m.optimizer.step()
+    m.optimizer.zero_grad(set_to_none=True)
+    return m
+
+
+def _moments(m, name):
+    for g in m.optimizer.param_groups:
+        if g["name"] == name:
+            return m.optimizer.state[g["params"][0]]
+
+
+def test_clone_split_prune_counts_and_state():
+    m = _model()
+    P = 40
+    xyz0, rot0, sc0 = m._xyz.detach().clone(), m._rotation.detach().clone(), m.get_scaling.detach().clone()
+    m.max_radii2D = torch.zeros(P)
+    # gradient statistics: rows 0..9 above the threshold (5 small -> clone, 5 large -> split), row 39 NaN (0/0)
+    m.xyz_gradient_accum = torch.zeros((P, 1))
+    m.denom = torch.ones((P, 1))
+    m.xyz_gradient_accum[:10] = 1.0
+    m.denom[39] = 0.0
+    with torch.no_grad():
+        m._opacity[20] = -10.0  # transparent -> pruned
+    torch.manual_seed(0)
+    m.densify_and_prune(max_grad=0.5, min_opacity=0.005, extent=1.0, max_screen_size=None)
+    # 40 + 5 clones + 2*5 children - 5 split parents - 1 transparent = 49
+    assert m._xyz.shape[0] == 49
+    for t in (m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation):
+        assert t.shape[0] == 49 and t.requires_grad
+    assert m.xyz_gradient_accum.shape == (49, 1) and not m.xyz_gradient_accum.any() and not m.denom.any()
+    assert m.max_radii2D.shape == (49,)
+    # optimiser: parameters rebound, moments follow the rows (kept rows keep theirs, new rows start at zero)
+    for g in m.optimizer.param_groups:
+        p = g["params"][0]
+        assert p is getattr(m, {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                                "scaling": "_scaling", "rotation": "_rotation"}[g["name"]])
+        st = m.optimizer.state[p]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape and float(st["step"]) == 1
+    ea = _moments(m, "xyz")["exp_avg"]
+    n_kept = 40 - 5 - 1
+    assert (ea[:n_kept] != 0).all() and not ea[n_kept:].any()
+    # survivors in original order: small rows 0,2,4,6,8 stay, large rows 1,3,5,7,9 are gone, row 20 is gone
+    kept_idx = [i for i in range(40) if i not in (1, 3, 5, 7, 9, 20)]
+    assert torch.allclose(m._xyz.detach()[:n_kept], xyz0[kept_idx])
+    # clones are exact copies of rows 0,2,4,6,8
+    assert torch.equal(m._xyz.detach()[n_kept:n_kept + 5], xyz0[[0, 2, 4, 6, 8]])
+    # children: N=2 per parent, scale / 1.6, same rotation, displaced inside the parent's plane
+    kids = m._xyz.detach()[n_kept + 5:]
+    parents = [1, 3, 5, 7, 9] * 2
+    assert torch.allclose(m.get_scaling.detach()[n_kept + 5:], sc0[parents] / 1.6, rtol=1e-5)
+    assert torch.equal(m._rotation.detach()[n_kept + 5:], rot0[parents])
+    normal = build_rotation(rot0[parents])[:, :, 2]
+    off = kids - xyz0[parents]
+    assert (off * normal).sum(1).abs().max() <= 1e-5 and off.norm(dim=1).max() <= 5 * 0.3 * 1.5
+
+
+def test_prune_by_screen_and_world_size_and_mip_toggle():
+    m = _model(P=12, seed=1)
+    m.xyz_gradient_accum = torch.zeros((12, 1))
+    m.denom = torch.ones((12, 1))
+    m.max_radii2D = torch.zeros(12)
+    m.max_radii2D[3] = 50.0
+    m.use_mip_filter = True
+    m.mip_filter = torch.full((12, 1), 10.0)  # would make every scale > 0.1 * extent if it were not switched off
+    m.densify_and_prune(max_grad=1e9, min_opacity=0.005, extent=1.0, max_screen_size=20)
+    # row 3 (screen size) and the six large rows (0.3 > 0.1 * extent) go; the mip filter is restored
+    assert m._xyz.shape[0] == 12 - 1 - 6 + (1 if 3 % 2 == 1 else 0)
+    assert m.use_mip_filter and m.mip_filter.shape[0] == m._xyz.shape[0]
+
+
+def test_reset_opacity_zeroes_moments():
+    m = _model(P=9)
+    with torch.no_grad():
+        m._opacity[0] = -8.0  # already below 0.01: unchanged
+    before = m.get_opacity.detach().clone()
+    old_param = m._opacity
+    m.reset_opacity()
+    assert m._opacity is not old_param
+    o = m.get_opacity.detach()
+    assert torch.allclose(o[1:], torch.full_like(o[1:], 0.01), atol=1e-6) and torch.allclose(o[0], before[0])
+    st = _moments(m, "opacity")
+    assert not st["exp_avg"].any() and not st["exp_avg_sq"].any() and float(st["step"]) == 1
+
+
+def test_compute_mip_filter():
+    from types import SimpleNamespace
+    m = _model(P=6)
+    with torch.no_grad():
+        m._xyz[:] = torch.tensor([[0, 0, 2.0], [0, 0, 4.0], [0, 0, -1.0], [100.0, 0, 1.0], [0.1, 0.1, 1.0], [0, 0, 0.1]])
+    cam = SimpleNamespace(R=np.eye(3, dtype=np.float32), T=np.zeros(3, np.float32), focal_x=100.0, focal_y=100.0,
+                          image_width=200, image_height=100)
+    cam2 = SimpleNamespace(R=np.eye(3, dtype=np.float32), T=np.array([0, 0, 1.0], np.float32), focal_x=50.0, focal_y=50.0,
+                           image_width=200, image_height=100)
+    m.compute_mip_filter([cam, cam2])
+    f = m.mip_filter[:, 0]
+    k = 0.2 ** 0.5 / 100.0
+    # closest valid depth over both cameras; points nobody sees get the largest valid distance
+    assert torch.allclose(f[0], torch.tensor(2.0 * k)) and torch.allclose(f[1], torch.tensor(4.0 * k))
+    assert torch.allclose(f[4], torch.tensor(1.0 * k)) and torch.allclose(f[5], torch.tensor(1.1 * k))
+    assert torch.allclose(f[2], f.max()) and torch.allclose(f[3], f.max())

@@ -108,3 +108,46 @@ def test_hip_training_tracks_cpu_checker_training(hip_lib):
     drift = (m_gpu._xyz.detach().cpu() - m_cpu._xyz.detach()).abs().mean()
     assert drift <= 0.1 * moved, (float(drift), float(moved))
     assert torch.equal(m_gpu.denom.cpu(), m_cpu.denom)
+
+
+def test_densify_on_gpu_then_keep_training(hip_lib):
+    """prune / clone / split on HIP tensors with FusedAdam's state, followed by more iterations of the product path."""
+    dev = torch.device("cuda:0")
+    cams = _cams(dev)
+    model = _model(0, dev, jitter=True)
+    model.training_setup()
+    from g4splat_amd.optim import FusedAdam
+    assert isinstance(model.optimizer, FusedAdam)
+    pipe = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+    gt = torch.rand((3, H, W), device=dev)
+
+    def iterate(n):
+        last = None
+        for it in range(n):
+            out = render(cams[it % 4], model, pipe, bg)
+            loss, _, _ = photometric_loss(out["render"], gt, 0.2)
+            loss.backward()
+            with torch.no_grad():
+                model.max_radii2D = torch.maximum(model.max_radii2D, out["radii"].float())
+                model.add_densification_stats(out["viewspace_points"], out["visibility_filter"])
+                model.optimizer.step()
+                model.optimizer.zero_grad(set_to_none=True)
+            last = float(loss.detach())
+        return last
+
+    iterate(6)
+    n0 = model.get_xyz.shape[0]
+    torch.manual_seed(0)
+    thr = float((model.xyz_gradient_accum / model.denom.clamp(min=1)).median())  # about half of the set qualifies
+    model.densify_and_prune(thr, 0.005, extent=2.0, max_screen_size=None)
+    n1 = model.get_xyz.shape[0]
+    assert n1 > n0
+    for p in model.parameters():
+        assert p.shape[0] == n1 and p.is_cuda
+        st = model.optimizer.state[p]
+        assert st["exp_avg"].shape == p.shape and float(st["step"]) == 6
+    model.reset_opacity()
+    assert float(model.get_opacity.detach().max()) <= 0.0100001
+    assert np.isfinite(iterate(6))
+    assert float(model.optimizer.state[model._xyz]["step"]) == 12
