@@ -45,7 +45,7 @@ def test_metric_resolution_vs_restatement_and_speed(hip_lib, capsys):
     x2 = img.clone().requires_grad_(True)
     rl, r1, rs = losses_ref.photometric_loss(x2, gt, 0.2)  # eager torch on the same GPU
     (3.0 * rl).backward()
-    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-5 and abs(float(l1) - float(r1)) <= 1e-6 and abs(float(ss) - float(rs)) <= 1e-5
+    assert abs(float(loss.detach()) - float(rl.detach())) <= 1e-5 and abs(float(l1) - float(r1.detach())) <= 1e-6 and abs(float(ss) - float(rs.detach())) <= 1e-5
     d = (x1.grad - x2.grad).abs().max()
     assert float(d) <= 1e-3 * float(x2.grad.abs().max())
     # bit-reproducible
