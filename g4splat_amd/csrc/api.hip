@@ -165,6 +165,7 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     out->ranges = im.ranges;
     out->final_T = im.final_T;
     out->n_contrib = im.n_contrib;
+    out->tile_order = im.tile_order;
     out->image_bytes = im.bytes;
     return G4S_OK;
 }

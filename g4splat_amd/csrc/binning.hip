@@ -327,6 +327,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int R, const uint64_t*
 // workgroup of the blend kernels and list lengths are very uneven, so dispatching the heavy tiles
 // first shortens the tail.  Single block: bucket histogram (descending) in LDS, scan, scatter; the
 // order inside a bucket is arbitrary (it cannot change any result, tiles are independent).
+// (An XCD-aware variant -- 8x8-tile macro-blocks assigned to the 8 XCDs round-robin, LPT inside each group,
+// groups interleaved so that workgroup b lands on XCD b % 8 next to its spatial neighbours -- was measured 1 %
+// SLOWER on S3: the blend kernels are VALU-bound, the splat records they share sit in the 256 MB MALL anyway,
+// and per-group ordering costs more balance than the L2 locality returns.)
 constexpr int ORDER_BUCKETS = 2048;
 __global__ void __launch_bounds__(1024) tile_order_kernel(int tiles, const uint32_t* __restrict__ ranges,
                                                           uint32_t* __restrict__ order) {

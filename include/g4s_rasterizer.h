@@ -152,6 +152,7 @@ typedef struct g4s_layout {
     size_t ranges;       /* tiles x (u32 start, u32 end) */
     size_t final_T;      /* 3N floats: T, M1, M2 */
     size_t n_contrib;    /* 2N u32: last contributor, median contributor */
+    size_t tile_order;   /* tiles x u32: workgroup id -> tile, longest instance list first */
     size_t image_bytes;
 } g4s_layout;
 

@@ -85,6 +85,7 @@ def hip_state(out, inp):
     st["entries"] = binning[L.entries:L.entries + 8 * nb].view(np.uint64)
     st["final_T"] = img[L.final_T:L.final_T + 12 * N].view(np.float32).reshape(3, N)
     st["n_contrib"] = img[L.n_contrib:L.n_contrib + 8 * N].view(np.uint32).reshape(2, N)
+    st["tile_order"] = img[L.tile_order:L.tile_order + 4 * tiles].view(np.uint32)
     return st
 
 

@@ -86,6 +86,11 @@ def test_stages_match_oracle(hip_lib, oracle_mod):
     kept, total = check_lists_against_oracle(st, orc, oracle_mod)
     assert kept == int(st["tiles_touched"].sum()) and total == o["R"]
     assert np.abs(st["final_T"] - orc.state("final_T")).max() <= OUT_ATOL
+    # workgroup -> tile map: a permutation, longest lists first (4-entry buckets)
+    order = st["tile_order"].astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(len(st["ranges"])))
+    n = (st["ranges"][:, 1] - st["ranges"][:, 0])[order].astype(np.int64)
+    assert np.all(np.diff(np.minimum(n >> 2, 2047)) <= 0)
     check_forward(h, o)
 
 
