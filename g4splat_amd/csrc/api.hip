@@ -161,6 +161,7 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     out->tiles_touched = g.tiles_touched;
     out->geom_bytes = g.bytes;
     out->entries = (passes & 1) ? b.ent_b : b.ent_a;
+    out->qhit = b.qhit;
     out->binning_bytes = b.bytes;
     out->ranges = im.ranges;
     out->final_T = im.final_T;
@@ -313,6 +314,7 @@ extern "C" int g4s_rasterizer_forward(
     ba.ranges = ranges; ba.tile_order = tile_order; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
     ba.qhit = qhit_ptr;
+    ba.box_only = getenv("G4S_BOX_ONLY") != nullptr;
     if (getenv("G4S_SKIP_BLEND")) return R;  // bring-up aid: leave the binning state for inspection
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");

@@ -30,13 +30,43 @@ __device__ __forceinline__ bool quad_misses_box(const float4 box, float qx, floa
     return box.x > qx + 7.0f || box.z < qx || box.y > qy + 7.0f || box.w < qy;
 }
 
+// true if no pixel of the quadrant can pass the alpha test: the quadrant rectangle [qx, qx+7] x [qy, qy+7] meets
+// neither the low-pass disk around the splat centre nor the (enlarged) cutoff ellipse of record quads 6..7
+// (centre e, unit major axis u, 1/a^2, 1/b^2).  The minimum of the convex form over a rectangle that does not
+// contain the centre lies on its boundary: four 1-D minimisations with clamping; the form itself is evaluated in
+// the ellipse's eigenframe, where it is a sum of two squares (no cancellation for needles).
+__device__ __forceinline__ bool quad_misses_region(const float4 q0, const float4 q6, const float4 q7, float qx, float qy) {
+    const float x1 = qx + 7.0f, y1 = qy + 7.0f;
+    // low-pass disk
+    const float ddx = fmaxf(fmaxf(qx - q0.x, q0.x - x1), 0.0f), ddy = fmaxf(fmaxf(qy - q0.y, q0.y - y1), 0.0f);
+    if (ddx * ddx + ddy * ddy <= q7.z) return false;
+    if (q7.w == 0.0f) return false;  // no ellipse: the bounding box decided
+    const float ux = q6.z, uy = q6.w, ia = q7.x, ib = q7.y;
+    const float ax0 = qx - q6.x, ax1 = x1 - q6.x, ay0 = qy - q6.y, ay1 = y1 - q6.y;  // rectangle relative to e
+    if (ax0 <= 0.0f && ax1 >= 0.0f && ay0 <= 0.0f && ay1 >= 0.0f) return false;      // centre inside
+    // M = ia u u^T + ib v v^T, v = (-uy, ux): all three entries are sums of non-negative terms except m12
+    const float m11 = ia * ux * ux + ib * uy * uy, m22 = ia * uy * uy + ib * ux * ux, m12 = (ia - ib) * ux * uy;
+    const float r22 = m12 / m22, r11 = m12 / m11;
+    auto form = [&](float dx, float dy) {
+        const float t1 = dx * ux + dy * uy, t2 = dy * ux - dx * uy;
+        return ia * t1 * t1 + ib * t2 * t2;
+    };
+    auto clampf = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+    const float f0 = form(ax0, clampf(-r22 * ax0, ay0, ay1));  // edge x = x0: dy* = -m12 dx / m22
+    const float f1 = form(ax1, clampf(-r22 * ax1, ay0, ay1));
+    const float f2 = form(clampf(-r11 * ay0, ax0, ax1), ay0);  // edge y = y0: dx* = -m12 dy / m11
+    const float f3 = form(clampf(-r11 * ay1, ax0, ax1), ay1);
+    return fminf(fminf(f0, f1), fminf(f2, f3)) > 1.0f;
+}
+
 // ---------------------------------------------------------------------------------------
 // K6 forward
 
 constexpr int FWD_BATCH = 256;
 
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
-    __shared__ float4 s_rec[REC_QUADS][FWD_BATCH];
+    __shared__ float4 s_rec[BLEND_QUADS][FWD_BATCH];
+    __shared__ uint32_t s_rel[FWD_BATCH];  // bit q: the entry's alpha-cutoff region can reach quadrant q
     __shared__ unsigned long long s_hit[FWD_BATCH / 64][4];  // [group][quadrant]: entries some pixel blended
     const int tile = (int)a.tile_order[blockIdx.x];
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
@@ -44,7 +74,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
     const int qx = tile_x * TILE + (wv & 1) * 8, qy = tile_y * TILE + (wv >> 1) * 8;
     const int px = qx + (lane & 7), py = qy + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
-    const float pxf = (float)px, pyf = (float)py, qxf = (float)qx, qyf = (float)qy;
+    const float pxf = (float)px, pyf = (float)py;
     const size_t N = (size_t)a.W * a.H;
     const size_t pix_id = (size_t)a.W * py + px;
 
@@ -69,18 +99,32 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
         if ((int)threadIdx.x < m) {
             const uint64_t e = a.entries[r0 + b0 + threadIdx.x];
             const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
+            float4 rq[REC_QUADS];
 #pragma unroll
-            for (int i = 0; i < REC_QUADS; i++) s_rec[i][threadIdx.x] = r[i];
+            for (int i = 0; i < REC_QUADS; i++) rq[i] = r[i];
+#pragma unroll
+            for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][threadIdx.x] = rq[i];
+            // Which of the tile's four quadrants can this splat reach at all?  Decided ONCE per staged entry (not
+            // once per quadrant wave): bounding box first, then the exact region (low-pass disk + cutoff ellipse).
+            uint32_t relmask = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float bx = (float)(tile_x * TILE + (q & 1) * 8), by = (float)(tile_y * TILE + (q >> 1) * 8);
+                bool rel = !quad_misses_box(rq[5], bx, by);
+                if (rel && !a.box_only) rel = !quad_misses_region(rq[0], rq[6], rq[7], bx, by);
+                relmask |= rel ? (1u << q) : 0u;
+            }
+            s_rel[threadIdx.x] = relmask;
         }
         if (threadIdx.x < (FWD_BATCH / 64) * 4) (&s_hit[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
         if (__ballot(Tt != 0.0f) != 0ull) {
-        // Each group of 64 staged entries is first filtered against this wave's quadrant with one
-        // box test per lane + a ballot; only entries whose alpha-cutoff box touches the quadrant are
-        // visited (scalar bit scan), so a rejected entry costs ~1/64 of a loop iteration.
+        // Each group of 64 staged entries is filtered for this wave's quadrant with one bit test per lane + a
+        // ballot; only entries whose region touches the quadrant are visited (scalar bit scan), so a rejected
+        // entry costs ~1/64 of a loop iteration.
         for (int g0 = 0; g0 < m; g0 += 64) {
             const int jl = g0 + lane;
-            const bool rel = jl < m && !quad_misses_box(s_rec[5][jl < FWD_BATCH ? jl : 0], qxf, qyf);
+            const bool rel = jl < m && ((s_rel[jl < FWD_BATCH ? jl : 0] >> wv) & 1u);
             uint64_t todo = __ballot(rel);
             uint64_t hit = 0;  // wave-uniform: entries of this group blended by some pixel of this quadrant
             bool live = true;  // wave-uniform: some pixel of the quadrant is not saturated yet
@@ -186,7 +230,7 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // waves_per_eu(3): 168 VGPRs instead of the 171 the allocator would take -> 3 resident waves per SIMD instead of 2
 // (two 4-byte spills land in the per-batch prologue, not in the entry loop); measured 1.86 -> 1.51 ms on S3.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[REC_QUADS - 1][BWD_BATCH];  // the box quad is not needed here
+    __shared__ float4 s_rec[BLEND_QUADS][BWD_BATCH];  // the culling quads are not needed here
     __shared__ uint32_t s_slot[BWD_BATCH];
 
     const int tile = (int)a.tile_order[blockIdx.x];
@@ -260,12 +304,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             const uint32_t pos_l = (uint32_t)(hi - 1 - lane);
             const uint64_t e = a.entries[r0 + pos_l];
             const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
-            float4 rq[REC_QUADS - 1];
+            float4 rq[BLEND_QUADS];
 #pragma unroll
-            for (int i = 0; i < REC_QUADS - 1; i++) rq[i] = r[i];  // all loads in flight before any LDS store
+            for (int i = 0; i < BLEND_QUADS; i++) rq[i] = r[i];  // all loads in flight before any LDS store
             const float4 q0 = rq[0];
 #pragma unroll
-            for (int i = 0; i < REC_QUADS - 1; i++) s_rec[i][lane] = rq[i];
+            for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
             s_slot[lane] = __float_as_uint(q0.z) + entry_k(e);
         }
         __syncthreads();

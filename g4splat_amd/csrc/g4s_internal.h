@@ -9,8 +9,9 @@
 namespace g4s {
 
 constexpr int TILE = 16;           // tile edge in pixels (part of the output definition, auxiliary.h:66-76)
-constexpr int REC_FLOATS = 24;     // per-Gaussian splat record, 96 B = 6 x float4 (layout below)
+constexpr int REC_FLOATS = 32;     // per-Gaussian splat record, 128 B = 8 x float4 (layout below)
 constexpr int REC_QUADS = REC_FLOATS / 4;
+constexpr int BLEND_QUADS = 5;     // q0..q4: what the per-pixel arithmetic needs (q5..q7 only steer culling)
 constexpr int GRAD_FLOATS = 18;    // gradient terms per instance (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
 constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 16-byte aligned; last two unused)
 // Splat record (written by the forward preprocess, read by emit / blend / backward):
@@ -19,6 +20,9 @@ constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 1
 //   q2 = (Tu.x, Tu.y, Tu.z, Tv.x)   q3 = (Tv.y, Tv.z, Tw.x, Tw.y)   q4 = (Tw.z, r, g, b)
 //   q5 = conservative pixel bounding box (x0, y0, x1, y1) of the region where this splat can pass
 //        the 1/255 alpha test (empty: x0 > x1)
+//   q6 = (ex, ey, ux, uy), q7 = (1/a^2, 1/b^2, r2, valid): the same region exactly -- the union of the ellipse
+//        (centre e, unit major axis u, semi-axes a >= b) that the alpha-cutoff disk of the splat projects to and of
+//        the low-pass disk |pixel - centre|^2 <= r2 -- slightly enlarged; valid = 0: no ellipse, use the box
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 constexpr int SORT_CHUNK_MAX = 2048;  // keys per wave-private radix chunk (upper bound)
 // Chunk length for n keys: one wave per chunk; aim for ~8 waves per CU so that the per-wave serial
@@ -163,6 +167,7 @@ struct BlendFwdArgs {
     float* final_T;
     uint32_t* n_contrib;
     uint8_t* qhit;  // per sorted instance: bit q set if some pixel of quadrant q blended it (pre-zeroed)
+    int box_only;   // experiments / tests (G4S_BOX_ONLY): skip quadrants by the bounding box only
     float* out_color;
     float* out_others;
 };

@@ -100,6 +100,78 @@ __device__ __forceinline__ void alpha_cutoff_box(const float* T, float cx, float
     box = make_float4(lo_x, lo_y, hi_x, hi_y);
 }
 
+// The same region, exactly: rho3d <= t is the set of pixels (x, y) with  p.x^2 + p.y^2 - t p.z^2 <= 0  where
+// p = k x l = Tu x Tv - x (Tw x Tv) - y (Tu x Tw) is LINEAR in the pixel, i.e. a conic.  When it is an ellipse it is
+// returned in its eigenframe -- centre e, unit major axis u, inverse squared semi-axes 1/a^2 <= 1/b^2 -- so that
+// the blend kernels can evaluate  ((d.u)/a)^2 + ((d.v)/b)^2 <= 1  without cancellation even for needles with an
+// aspect ratio of 10^4 (the expanded form m11 dx^2 + 2 m12 dx dy + m22 dy^2 loses all digits there).  Both
+// semi-axes are enlarged: r -> 1.002 sqrt(r^2 + 0.75^2) (0.2 % + three quarters of a pixel in quadrature; that
+// absorbs the float storage of e and the per-pixel rounding of the blend loops and keeps the minor axis above
+// 0.75 px).  Also the squared radius of the low-pass disk (rho2d = 2 |pixel - centre|^2 <= t).  Evaluated in
+// double, once per visible Gaussian.  out[0..7] = ex, ey, ux, uy, 1/a^2, 1/b^2, r2, valid (1 / 0).
+struct CutoffConic {
+    double ex, ey, ux, uy, a2, b2;  // centre, unit major axis, squared semi-axes
+};
+// the conic  p.x^2 + p.y^2 - t p.z^2 <= 0  as an ellipse; false if it is not one (or is empty)
+__device__ bool cutoff_conic(const double* A, const double* B, const double* D, double t, CutoffConic& c) {
+    auto dotg = [t](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] - t * a[2] * b[2]; };
+    const double aa = dotg(A, A), ab = dotg(A, B), bb = dotg(B, B), a0 = dotg(A, D), b0 = dotg(B, D), c0 = dotg(D, D);
+    const double det = aa * bb - ab * ab;
+    if (!(aa > 0.0) || !(bb > 0.0) || !(det > 0.0)) return false;
+    c.ex = (a0 * bb - b0 * ab) / det;
+    c.ey = (b0 * aa - a0 * ab) / det;
+    const double kappa = a0 * c.ex + b0 * c.ey - c0;  // -Q(e):  (x - e)^T H (x - e) <= kappa
+    if (!(kappa > 0.0)) return false;
+    // eigen-decomposition of H = [aa ab; ab bb]: small eigenvalue <-> major axis
+    const double tr = aa + bb, disc = sqrt(fmax((aa - bb) * (aa - bb) + 4.0 * ab * ab, 0.0));
+    const double lmax = 0.5 * (tr + disc), lmin = det / lmax;  // (tr - disc) / 2 without the cancellation
+    if (!(lmin > 0.0)) return false;
+    double ux, uy;  // eigenvector of lmin
+    if (fabs(ab) > 1e-300) {
+        ux = lmin - bb; uy = ab;
+        if (fabs(aa - lmin) > fabs(bb - lmin)) { ux = ab; uy = lmin - aa; }
+    } else {
+        ux = aa <= bb ? 1.0 : 0.0; uy = aa <= bb ? 0.0 : 1.0;
+    }
+    const double un = sqrt(ux * ux + uy * uy);
+    if (!(un > 0.0)) return false;
+    c.ux = ux / un; c.uy = uy / un;
+    c.a2 = kappa / lmin; c.b2 = kappa / lmax;
+    return true;
+}
+
+__device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, float* out) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = 0.0f;
+    const float thr = 2.0f * logf(255.0f * opa);
+    if (!(thr > 0.0f)) return;
+    const double t = (double)thr * 1.001 + 1e-3;
+    out[6] = (float)(0.5 * t * 1.001 + 0.01);
+    const double Tu[3] = {T[0], T[1], T[2]}, Tv[3] = {T[3], T[4], T[5]}, Tw[3] = {T[6], T[7], T[8]};
+    auto cross = [](const double* a, const double* b, double* c) {
+        c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double A[3], B[3], D[3];
+    cross(Tw, Tv, A);
+    cross(Tu, Tw, B);
+    cross(Tu, Tv, D);
+    // The conic of a needle seen obliquely is nearly degenerate: its long axis then depends on the 7th digit of t
+    // and of T, i.e. on rounding the blend loops do not share.  Accept the ellipse only where it is well
+    // conditioned: growing the cutoff by 1e-4 (ten times any rounding in the per-pixel evaluation) must move the
+    // centre by less than a tenth of a pixel and the axes by less than 0.1 %; the larger of the two is used.
+    CutoffConic c0, c1;
+    if (!cutoff_conic(A, B, D, t, c0) || !cutoff_conic(A, B, D, t * (1.0 + 1e-4), c1)) return;
+    const double shift2 = (c1.ex - c0.ex) * (c1.ex - c0.ex) + (c1.ey - c0.ey) * (c1.ey - c0.ey);
+    if (!(shift2 < 0.01) || !(c1.a2 < c0.a2 * 1.002) || !(c1.b2 < c0.b2 * 1.002 + 1e-6) || !(c1.a2 >= c0.a2 * 0.999)) return;
+    const double a2 = c1.a2 + 0.5625, b2 = c1.b2 + 0.5625;  // semi-axes^2 + 0.75^2
+    const double s2 = 1.002 * 1.002;
+    const double vals[6] = {c1.ex, c1.ey, c1.ux, c1.uy, 1.0 / (a2 * s2), 1.0 / (b2 * s2)};
+    for (int i = 0; i < 6; i++)
+        if (!(fabs(vals[i]) < 1e30)) return;  // NaN / overflow: no ellipse
+    for (int i = 0; i < 6; i++) out[i] = (float)vals[i];
+    out[7] = 1.0f;
+}
+
 // Loads the 3*(deg+1)^2 active SH floats of Gaussian idx into registers.  vec16: the records are
 // 192 B ([16][3] floats) on a 16-byte aligned base, so they are fetched as 16-byte quads.
 __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int deg, bool vec16,
@@ -241,13 +313,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         rec[21] = box.y;
                         rec[22] = box.z;
                         rec[23] = box.w;
+                        if (touched != 0) alpha_cutoff_ellipse(T, opa, rec + 24);
                     }
                 }
             }
         }
-        float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * REC_QUADS;
+        // the record of a Gaussian with radii == 0 is never read (emit / blend follow the tile lists, the backward
+        // looks at radii first): writing only the visible ones saves 128 B x (P - V) of stores
+        if (radius_out > 0) {
+            float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * REC_QUADS;
 #pragma unroll
-        for (int i = 0; i < REC_QUADS; i++) out[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+            for (int i = 0; i < REC_QUADS; i++) out[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+        }
         a.clamped[idx] = (uint8_t)clamp_bits;
         a.tiles_touched[idx] = touched;
         a.radii[idx] = radius_out;

@@ -140,13 +140,14 @@ int g4s_knn_mean_dist(int P, const float* points, float* meanDists, char* worksp
  * callbacks.  Not part of the drop-in surface. */
 typedef struct g4s_layout {
     /* geometry chunk */
-    size_t rec;          /* P x 24 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb, box */
+    size_t rec;          /* P x 32 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb, box, cutoff ellipse */
     size_t clamped;      /* P x u8 (bit c = channel c clamped) */
     size_t depth_sorted; /* P x u32 Gaussian indices in (depth, index) order, culled ones last */
     size_t tiles_touched;/* P x u32 */
     size_t geom_bytes;
     /* binning chunk */
     size_t entries;      /* R x u64 sorted instances: tile<<48 | k<<32 | idx */
+    size_t qhit;         /* one byte per sorted instance: bit q = quadrant q of its tile blended it */
     size_t binning_bytes;
     /* image chunk */
     size_t ranges;       /* tiles x (u32 start, u32 end) */

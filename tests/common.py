@@ -75,14 +75,15 @@ def hip_state(out, inp):
     tiles = ((inp["W"] + 15) // 16) * ((inp["H"] + 15) // 16)
     R = int(out["R"])
     st = {}
-    st["rec"] = geom[L.rec:L.rec + P * 96].view(np.float32).reshape(P, 24)
-    st["rec_u32"] = geom[L.rec:L.rec + P * 96].view(np.uint32).reshape(P, 24)
+    st["rec"] = geom[L.rec:L.rec + P * 128].view(np.float32).reshape(P, 32)
+    st["rec_u32"] = geom[L.rec:L.rec + P * 128].view(np.uint32).reshape(P, 32)
     st["clamped"] = geom[L.clamped:L.clamped + P]
     st["depth_sorted"] = geom[L.depth_sorted:L.depth_sorted + 4 * P].view(np.uint32)
     st["tiles_touched"] = geom[L.tiles_touched:L.tiles_touched + 4 * P].view(np.uint32)
     st["ranges"] = img[L.ranges:L.ranges + 8 * tiles].view(np.uint32).reshape(tiles, 2)
     nb = int(st["tiles_touched"].sum())  # instances actually binned (<= R, the reference count)
     st["entries"] = binning[L.entries:L.entries + 8 * nb].view(np.uint64)
+    st["qhit"] = binning[L.qhit:L.qhit + nb].copy()
     st["final_T"] = img[L.final_T:L.final_T + 12 * N].view(np.float32).reshape(3, N)
     st["n_contrib"] = img[L.n_contrib:L.n_contrib + 8 * N].view(np.uint32).reshape(2, N)
     st["tile_order"] = img[L.tile_order:L.tile_order + 4 * tiles].view(np.uint32)

@@ -336,3 +336,52 @@ def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
             check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
         for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
             assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, (tag, name)
+
+
+def test_quadrant_culling_never_changes_a_result(hip_lib):
+    """The exact cutoff-ellipse test of the forward only skips quadrants no pixel of which can pass the alpha test:
+    with it switched off (G4S_BOX_ONLY: bounding box only) every output, the blend state and the per-quadrant
+    contribution masks must be bit-identical -- on random small scenes (thin, huge, tiny, translucent splats, wide
+    fields of view) and at the metric's size."""
+    import os
+    import torch
+    from g4splat_amd import synthetic
+
+    def both(inp):
+        outs = []
+        g = cotangents(inp["H"], inp["W"], seed=7)
+        for box_only in (False, True):
+            if box_only:
+                os.environ["G4S_BOX_ONLY"] = "1"
+            try:
+                h = run_hip(inp, g)  # the gradients depend on the contribution masks the forward records
+            finally:
+                os.environ.pop("G4S_BOX_ONLY", None)
+            st = hip_state(h, inp)
+            outs.append([h["color"], h["others"], st["final_T"].copy(), st["n_contrib"].copy()] +
+                        [h["grads"][k] for k in sorted(h["grads"])])
+        return outs
+
+    for seed in range(150):
+        rng = np.random.default_rng(500 + seed)
+        inp = scene_inputs(P=int(rng.choice([50, 1500, 6000])), W=int(rng.choice([64, 177, 320])),
+                           H=int(rng.choice([48, 130, 200])), seed=500 + seed, D=int(rng.integers(0, 4)),
+                           scale_mul=float(rng.choice([0.2, 1.0, 3.0, 12.0])), opacity_max=float(rng.choice([0.05, 0.5, 1.0])),
+                           fov_deg=float(rng.uniform(30, 115)))
+        if seed % 3 == 0:  # needle-like splats: their cutoff conic is nearly degenerate
+            inp["scales"] = (inp["scales"] * np.array([[8.0, 0.1]], np.float32)).astype(np.float32)
+        elif seed % 3 == 1 and seed % 2 == 0:  # hair-thin and very long
+            inp["scales"] = (inp["scales"] * np.array([[0.01, 40.0]], np.float32)).astype(np.float32)
+        a, b = both(inp)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), seed
+    P, W, H = 1_500_000, 1600, 1200
+    scene = synthetic.scene_room(P, seed=0)
+    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[6]
+    inp = dict(bg=np.zeros(3, np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
+               scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
+               view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+               H=H, W=W, sh=scene.shs, D=3, campos=cam.camera_center)
+    a, b = both(inp)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
