@@ -385,3 +385,17 @@ def test_quadrant_culling_never_changes_a_result(hip_lib):
     a, b = both(inp)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_hot_tiles(hip_lib, oracle_mod):
+    """Everything lands in a handful of tiles (lists of ~10^4 translucent instances each, far more than one staging
+    batch; no early saturation): the long-list paths of both blend kernels and of the per-Gaussian fold."""
+    inp = scene_inputs(P=60000, W=48, H=32, seed=77, D=1, opacity_max=0.03, scale_mul=4.0, fov_deg=110.0)
+    g = cotangents(32, 48, seed=5)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    st = hip_state(h, inp)
+    n = st["ranges"][:, 1] - st["ranges"][:, 0]
+    assert n.max() > 5000
+    check_forward(h, o)
+    check_grads(h, o)
