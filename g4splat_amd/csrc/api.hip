@@ -315,6 +315,7 @@ extern "C" int g4s_rasterizer_forward(
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
     ba.qhit = qhit_ptr;
     ba.box_only = getenv("G4S_BOX_ONLY") != nullptr;
+    ba.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
     if (getenv("G4S_SKIP_BLEND")) return R;  // bring-up aid: leave the binning state for inspection
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");
@@ -383,6 +384,7 @@ extern "C" int g4s_rasterizer_backward(
         bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
+        bb.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
         bb.dbg = getenv("G4S_BWD_DBG") ? atoi(getenv("G4S_BWD_DBG")) : 0;
         { ProfScope ps(PF_BLEND_BWD, stream); launch_blend_bwd(bb, stream); }
         CHECK_LAUNCH("blend_bwd");

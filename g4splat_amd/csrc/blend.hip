@@ -64,6 +64,54 @@ __device__ __forceinline__ bool quad_misses_region(const float4 q0, const float4
 
 constexpr int FWD_BATCH = 256;
 
+struct FwdPixel {
+    // Tt = running transmittance while the pixel is live, 0 once it is saturated (forward.cu:327,399 `done`) or
+    // when it lies outside the image: a dead pixel then fails `test_T >= 1e-4` by itself, so the loop needs no
+    // per-lane `done` predicate, and "all 64 pixels dead" is one v_cmp of Tt against 0.  T_done keeps the
+    // transmittance a saturated pixel had when it stopped (the value the reference leaves in T).
+    float Tt, T_done;
+    uint32_t last_contributor, median_contributor;
+    float C0, C1, C2, N0, N1, N2, Dd, M1, M2, distortion, median_depth;
+};
+constexpr float FWD_MSCALE = FAR_N / (FAR_N - NEAR_N);
+constexpr float FWD_DMD_K = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m(depth) = mscale - dmd_k / depth
+
+// one pixel against one staged splat (forward.cu:349-433).  `nolp` is wave-uniform (see eval_pair).
+__device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, float pyf, const float4 q0, const float4 q1,
+                                          const float4 q2, const float4 q3, const float4 q4, uint32_t contributor) {
+    PairEval e;
+    if (eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e)) {
+        const float alpha = e.alpha, depth = e.depth;
+        const float T = p.Tt;
+        const float test_T = T * (1 - alpha);
+        if (test_T < 0.0001f) {
+            if (T != 0.0f) p.T_done = T;
+            p.Tt = 0.0f;
+        } else {
+            const float w = alpha * T;
+            const float A = 1 - T;
+            const float md = fmaf(-FWD_DMD_K, __builtin_amdgcn_rcpf(depth), FWD_MSCALE);
+            const float md2 = md * md;
+            p.distortion = fmaf(fmaf(-(md + md), p.M1, fmaf(md2, A, p.M2)), w, p.distortion);
+            p.Dd = fmaf(depth, w, p.Dd);
+            p.M1 = fmaf(md, w, p.M1);
+            p.M2 = fmaf(md2, w, p.M2);
+            if (T > 0.5f) {
+                p.median_depth = depth;
+                p.median_contributor = contributor;
+            }
+            p.N0 = fmaf(q1.x, w, p.N0);
+            p.N1 = fmaf(q1.y, w, p.N1);
+            p.N2 = fmaf(q1.z, w, p.N2);
+            p.C0 = fmaf(q4.y, w, p.C0);
+            p.C1 = fmaf(q4.z, w, p.C1);
+            p.C2 = fmaf(q4.w, w, p.C2);
+            p.Tt = test_T;
+            p.last_contributor = contributor;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLEND_QUADS][FWD_BATCH];
     __shared__ uint32_t s_rel[FWD_BATCH];  // bit q: the entry's alpha-cutoff region can reach quadrant q
@@ -81,20 +129,13 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
     const uint32_t r0 = a.ranges[2 * tile], r1 = a.ranges[2 * tile + 1];
     const int n = (int)(r1 - r0);
 
-    // Tt = running transmittance while the pixel is live, 0 once it is saturated (forward.cu:327,399 `done`) or
-    // when it lies outside the image: a dead pixel then fails `test_T >= 1e-4` by itself, so the loop needs no
-    // per-lane `done` predicate, and "all 64 pixels dead" is one v_cmp of Tt against 0.  T_done keeps the
-    // transmittance a saturated pixel had when it stopped (the value the reference leaves in T).
-    float Tt = inside ? 1.0f : 0.0f, T_done = 1.0f;
-    uint32_t last_contributor = 0, median_contributor = 0;
-    float C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0;
-    float Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
-    const float mscale = FAR_N / (FAR_N - NEAR_N);
-    const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m(depth) = mscale - dmd_k / depth
+    FwdPixel st{};
+    st.Tt = inside ? 1.0f : 0.0f;
+    st.T_done = 1.0f;
 
     for (int b0 = 0; b0 < n; b0 += FWD_BATCH) {
         // end if the entire tile is saturated (forward.cu:327)
-        if (__syncthreads_count(Tt == 0.0f) == 256) break;
+        if (__syncthreads_count(st.Tt == 0.0f) == 256) break;
         const int m = imin_(FWD_BATCH, n - b0);
         if ((int)threadIdx.x < m) {
             const uint64_t e = a.entries[r0 + b0 + threadIdx.x];
@@ -114,18 +155,22 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
                 if (rel && !a.box_only) rel = !quad_misses_region(rq[0], rq[6], rq[7], bx, by);
                 relmask |= rel ? (1u << q) : 0u;
             }
+            // bit 4: this splat's record says the low-pass exponent never matters (eval_pair's nolp)
+            if (!a.no_fastpath && (__float_as_uint(rq[0].w) & REC_NO_LOWPASS)) relmask |= 16u;
             s_rel[threadIdx.x] = relmask;
         }
         if (threadIdx.x < (FWD_BATCH / 64) * 4) (&s_hit[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
-        if (__ballot(Tt != 0.0f) != 0ull) {
+        if (__ballot(st.Tt != 0.0f) != 0ull) {
         // Each group of 64 staged entries is filtered for this wave's quadrant with one bit test per lane + a
         // ballot; only entries whose region touches the quadrant are visited (scalar bit scan), so a rejected
         // entry costs ~1/64 of a loop iteration.
         for (int g0 = 0; g0 < m; g0 += 64) {
             const int jl = g0 + lane;
-            const bool rel = jl < m && ((s_rel[jl < FWD_BATCH ? jl : 0] >> wv) & 1u);
+            const uint32_t rbits = s_rel[jl < FWD_BATCH ? jl : 0];
+            const bool rel = jl < m && ((rbits >> wv) & 1u);
             uint64_t todo = __ballot(rel);
+            const uint64_t nolp_mask = __ballot((rbits & 16u) != 0);  // wave-uniform, one bit per staged entry
             uint64_t hit = 0;  // wave-uniform: entries of this group blended by some pixel of this quadrant
             bool live = true;  // wave-uniform: some pixel of the quadrant is not saturated yet
             while (todo) {
@@ -135,40 +180,11 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
                 // `contributor` of the reference = 1-based list position (forward.cu:349)
                 const uint32_t contributor = (uint32_t)(b0 + j + 1);
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-                PairEval e;
-                if (eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e)) {
-                    const float alpha = e.alpha, depth = e.depth;
-                    const float T = Tt;
-                    const float test_T = T * (1 - alpha);
-                    if (test_T < 0.0001f) {
-                        if (T != 0.0f) T_done = T;
-                        Tt = 0.0f;
-                    } else {
-                        const float w = alpha * T;
-                        const float A = 1 - T;
-                        const float md = fmaf(-dmd_k, __builtin_amdgcn_rcpf(depth), mscale);
-                        const float md2 = md * md;
-                        distortion = fmaf(fmaf(-(md + md), M1, fmaf(md2, A, M2)), w, distortion);
-                        Dd = fmaf(depth, w, Dd);
-                        M1 = fmaf(md, w, M1);
-                        M2 = fmaf(md2, w, M2);
-                        if (T > 0.5f) {
-                            median_depth = depth;
-                            median_contributor = contributor;
-                        }
-                        N0 = fmaf(q1.x, w, N0);
-                        N1 = fmaf(q1.y, w, N1);
-                        N2 = fmaf(q1.z, w, N2);
-                        C0 = fmaf(q4.y, w, C0);
-                        C1 = fmaf(q4.z, w, C1);
-                        C2 = fmaf(q4.w, w, C2);
-                        Tt = test_T;
-                        last_contributor = contributor;
-                    }
-                }
+                const bool nolp = (nolp_mask >> bit) & 1ull;  // scalar
+                fwd_visit(st, nolp, pxf, pyf, q0, q1, q2, q3, q4, contributor);
                 // blended by some pixel <=> some pixel's last_contributor is this entry
-                if (__ballot(last_contributor == contributor) != 0ull) hit |= 1ull << bit;
-                live = __ballot(Tt != 0.0f) != 0ull;
+                if (__ballot(st.last_contributor == contributor) != 0ull) hit |= 1ull << bit;
+                live = __ballot(st.Tt != 0.0f) != 0ull;
                 if (!live) break;
             }
             if (lane == 0 && hit) s_hit[g0 >> 6][wv] = hit;
@@ -184,23 +200,23 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
             if (nib) a.qhit[r0 + b0 + threadIdx.x] = (uint8_t)nib;
         }
     }
-    const float T = Tt != 0.0f ? Tt : T_done;
+    const float T = st.Tt != 0.0f ? st.Tt : st.T_done;
     if (inside) {
         a.final_T[pix_id] = T;
-        a.final_T[pix_id + N] = M1;
-        a.final_T[pix_id + 2 * N] = M2;
-        a.n_contrib[pix_id] = last_contributor;
-        a.n_contrib[pix_id + N] = median_contributor;
-        a.out_color[pix_id] = C0 + T * a.bg[0];
-        a.out_color[pix_id + N] = C1 + T * a.bg[1];
-        a.out_color[pix_id + 2 * N] = C2 + T * a.bg[2];
-        a.out_others[pix_id + 0 * N] = Dd;            // DEPTH_OFFSET
+        a.final_T[pix_id + N] = st.M1;
+        a.final_T[pix_id + 2 * N] = st.M2;
+        a.n_contrib[pix_id] = st.last_contributor;
+        a.n_contrib[pix_id + N] = st.median_contributor;
+        a.out_color[pix_id] = st.C0 + T * a.bg[0];
+        a.out_color[pix_id + N] = st.C1 + T * a.bg[1];
+        a.out_color[pix_id + 2 * N] = st.C2 + T * a.bg[2];
+        a.out_others[pix_id + 0 * N] = st.Dd;            // DEPTH_OFFSET
         a.out_others[pix_id + 1 * N] = 1 - T;         // ALPHA_OFFSET
-        a.out_others[pix_id + 2 * N] = N0;            // NORMAL_OFFSET..+2
-        a.out_others[pix_id + 3 * N] = N1;
-        a.out_others[pix_id + 4 * N] = N2;
-        a.out_others[pix_id + 5 * N] = median_depth;  // MIDDEPTH_OFFSET
-        a.out_others[pix_id + 6 * N] = distortion;    // DISTORTION_OFFSET
+        a.out_others[pix_id + 2 * N] = st.N0;            // NORMAL_OFFSET..+2
+        a.out_others[pix_id + 3 * N] = st.N1;
+        a.out_others[pix_id + 4 * N] = st.N2;
+        a.out_others[pix_id + 5 * N] = st.median_depth;  // MIDDEPTH_OFFSET
+        a.out_others[pix_id + 6 * N] = st.distortion;    // DISTORTION_OFFSET
     }
 }
 
@@ -296,6 +312,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         // every passing entry below last_contributor was blended), so this mask is exact: entries and
         // quadrants without contribution are never touched.
         uint32_t qmask = 0;
+        bool nolp_l = false;
         if (lane < m) {
             const uint32_t pos_l = (uint32_t)(hi - 1 - lane);
             qmask = a.qhit[r0 + pos_l];
@@ -308,6 +325,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) rq[i] = r[i];  // all loads in flight before any LDS store
             const float4 q0 = rq[0];
+            nolp_l = !a.no_fastpath && (__float_as_uint(q0.w) & REC_NO_LOWPASS) != 0;
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
             s_slot[lane] = __float_as_uint(q0.z) + entry_k(e);
@@ -315,10 +333,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         __syncthreads();
 
         uint64_t todo = __ballot(qmask != 0);
+        const uint64_t nolp_mask = __ballot(nolp_l);  // wave-uniform: entries whose low-pass exponent never matters
         while (todo) {
             const int j = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)qmask, j);  // wave-uniform
+            const bool nolp = (nolp_mask >> j) & 1ull;                               // scalar
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
             float g[GRAD_STRIDE];
@@ -332,8 +352,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
                 bool act = pos < x.last_c;
-                if (act)
-                    act = eval_pair(pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                if (act) act = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
                 // (qhit is exact, so some pixel of the quadrant is active; no wave vote needed)
                 if (act) {
                     const float G = e.G, alpha = e.alpha, c_d = e.depth;
@@ -374,7 +393,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
 
-                    if (e.rho3d <= e.rho2d) {
+                    if (e.in3d) {
                         const float mG = dL_dG * -G;
                         const float dL_dsx = fmaf(mG, e.sx, dL_dz * q3.z);
                         const float dL_dsy = fmaf(mG, e.sy, dL_dz * q3.w);

@@ -220,10 +220,6 @@ __device__ __forceinline__ void tight_tile_rect(const float4 box, int x0, int y0
     }
 }
 
-#ifndef G4S_FAST_DIV
-#define G4S_FAST_DIV 1
-#endif
-
 constexpr float NEAR_N = 0.2f;    // auxiliary.h:37
 constexpr float FAR_N = 100.0f;   // auxiliary.h:38
 constexpr float FILTER_INV_SQUARE = 2.0f;  // auxiliary.h:39
@@ -232,9 +228,57 @@ constexpr float FILTER_INV_SQUARE = 2.0f;  // auxiliary.h:39
 // The fmaf placement is the contract shared with the oracle (oracle/surfel_oracle.c eval_pair).
 struct PairEval {
     float sx, sy, pz, inv_pz, kx, ky, kz, lx, ly, lz, rho3d, rho2d, depth, G, alpha, dx, dy;
+    bool in3d;  // the 3-D exponent was the smaller one (the low-pass fields rho2d, dx, dy are set only otherwise)
 };
-__device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float cy, float Tux, float Tuy, float Tuz,
-                                          float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz,
+constexpr uint32_t REC_NO_LOWPASS = 0x80000000u;  // bit 31 of the record's tile-count word (q0.w), see below
+
+// The ray-splat intersection of one pixel with one splat up to the two candidate exponents (forward.cu:349-372):
+//   rho3d = |s|^2 with s = p.xy / p.z, p = k x l;   rho2d = FilterInvSquare |centre - pixel|^2.
+// Returns false if p.z == 0.  s goes through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22
+// instructions); the only discrete decision that depends on it is `rho3d <= rho2d`: when the two are within 1e-5
+// relative of each other the exact quotient is recomputed, so the branch taken is the oracle's and the values
+// differ from it by ~1e-7 relative.  `tie` reports that case.
+__device__ __forceinline__ bool eval_rho(float pxf, float pyf, float cx, float cy, float Tux, float Tuy, float Tuz,
+                                         float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz, PairEval& e,
+                                         bool& tie) {
+    e.kx = fmaf(pxf, Twx, -Tux);
+    e.ky = fmaf(pxf, Twy, -Tuy);
+    e.kz = fmaf(pxf, Twz, -Tuz);
+    e.lx = fmaf(pyf, Twx, -Tvx);
+    e.ly = fmaf(pyf, Twy, -Tvy);
+    e.lz = fmaf(pyf, Twz, -Tvz);
+    const float ppx = fmaf(e.ky, e.lz, -(e.kz * e.ly));
+    const float ppy = fmaf(e.kz, e.lx, -(e.kx * e.lz));
+    const float ppz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
+    tie = false;
+    if (ppz == 0.0f) return false;
+    e.pz = ppz;
+    e.dx = cx - pxf;
+    e.dy = cy - pyf;
+    e.rho2d = FILTER_INV_SQUARE * fmaf(e.dx, e.dx, e.dy * e.dy);
+    const float inv = __builtin_amdgcn_rcpf(ppz);
+    e.inv_pz = inv;
+    e.sx = ppx * inv;
+    e.sy = ppy * inv;
+    e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
+    if (fabsf(e.rho3d - e.rho2d) <= 1e-5f * e.rho2d) {
+        tie = true;
+        e.sx = ppx / ppz;
+        e.sy = ppy / ppz;
+        e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
+    }
+    return true;
+}
+
+// One pixel against one splat: forward.cu:349-393 up to alpha.  `nolp` (wave-uniform) = the splat's record carries
+// REC_NO_LOWPASS: preprocess has checked, with this very arithmetic (eval_rho), that at every pixel where the
+// low-pass exponent rho2d could still pass the alpha test the 3-D exponent is the smaller one and is not in the tie
+// band -- so rho = rho3d, and the low-pass arithmetic (rho2d, the tie test, two selects: 11 instructions of the ~46)
+// is skipped with bit-identical results.  (Where rho2d is too large to pass, min(rho3d, rho2d) fails the alpha test
+// whichever of the two is used.)  The general extras sit inside one uniform branch that only refines values the
+// common code has already produced, so the two kinds of splat share everything else without register shuffling.
+__device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float cx, float cy, float Tux, float Tuy,
+                                          float Tuz, float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz,
                                           float opa, PairEval& e) {
     e.kx = fmaf(pxf, Twx, -Tux);
     e.ky = fmaf(pxf, Twy, -Tuy);
@@ -247,37 +291,29 @@ __device__ __forceinline__ bool eval_pair(float pxf, float pyf, float cx, float 
     const float ppz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
     if (ppz == 0.0f) return false;
     e.pz = ppz;
-    e.dx = cx - pxf;
-    e.dy = cy - pyf;
-    e.rho2d = FILTER_INV_SQUARE * fmaf(e.dx, e.dx, e.dy * e.dy);
-#if G4S_FAST_DIV
-    // s = p.xy / p.z through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22 instructions).
-    // The only discrete decision that depends on s is `rho3d <= rho2d`; when the two are within
-    // 1e-5 relative of each other the exact quotient is recomputed, so the branch taken is the
-    // oracle's and the values differ from it by ~1e-7 relative.
-    {
-        const float inv = __builtin_amdgcn_rcpf(ppz);
-        e.inv_pz = inv;
-        e.sx = ppx * inv;
-        e.sy = ppy * inv;
-        e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
-        if (fabsf(e.rho3d - e.rho2d) <= 1e-5f * e.rho2d) {
+    // s = p.xy / p.z through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22 instructions), see eval_rho
+    const float inv = __builtin_amdgcn_rcpf(ppz);
+    e.inv_pz = inv;
+    e.sx = ppx * inv;
+    e.sy = ppy * inv;
+    e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
+    e.in3d = true;
+    float rho = e.rho3d;
+    if (!nolp) {
+        e.dx = cx - pxf;
+        e.dy = cy - pyf;
+        e.rho2d = FILTER_INV_SQUARE * fmaf(e.dx, e.dx, e.dy * e.dy);
+        if (fabsf(e.rho3d - e.rho2d) <= 1e-5f * e.rho2d) {  // too close to call: exact quotient
             e.sx = ppx / ppz;
             e.sy = ppy / ppz;
             e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
         }
+        // rho = min(rho3d, rho2d) and the depth select share one compare.  (NaN rho3d -- 0 * inf when p.z is
+        // denormal -- takes the rho2d side in both, like fminf.)
+        e.in3d = e.rho3d <= e.rho2d;
+        rho = e.in3d ? e.rho3d : e.rho2d;
     }
-#else
-    e.inv_pz = __builtin_amdgcn_rcpf(ppz);
-    e.sx = ppx / ppz;
-    e.sy = ppy / ppz;
-    e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
-#endif
-    // rho = min(rho3d, rho2d) and the depth select share one compare.  (NaN rho3d -- 0 * inf when p.z is
-    // denormal -- takes the rho2d side in both, like fminf.)
-    const bool in3d = e.rho3d <= e.rho2d;
-    const float rho = in3d ? e.rho3d : e.rho2d;
-    e.depth = in3d ? fmaf(e.sx, Twx, e.sy * Twy) + Twz : Twz;
+    e.depth = e.in3d ? fmaf(e.sx, Twx, e.sy * Twy) + Twz : Twz;
     if (e.depth < NEAR_N) return false;
     // forward.cu:383-385 `power = -0.5 rho; if (power > 0) continue;` can never fire (rho is a sum of squares),
     // and exp(power) = exp2(rho * (-0.5 log2 e)): scaling by -0.5 is exact, so folding it into the constant

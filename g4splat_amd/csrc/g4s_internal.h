@@ -15,7 +15,7 @@ constexpr int BLEND_QUADS = 5;     // q0..q4: what the per-pixel arithmetic need
 constexpr int GRAD_FLOATS = 18;    // gradient terms per instance (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
 constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 16-byte aligned; last two unused)
 // Splat record (written by the forward preprocess, read by emit / blend / backward):
-//   q0 = (centre.x, centre.y, bits(inst_off), bits(tight tile count))
+//   q0 = (centre.x, centre.y, bits(inst_off), bits(tight tile count | REC_NO_LOWPASS))
 //   q1 = (normal.xyz (view space, flipped towards the camera), opacity)
 //   q2 = (Tu.x, Tu.y, Tu.z, Tv.x)   q3 = (Tv.y, Tv.z, Tw.x, Tw.y)   q4 = (Tw.z, r, g, b)
 //   q5 = conservative pixel bounding box (x0, y0, x1, y1) of the region where this splat can pass
@@ -168,6 +168,7 @@ struct BlendFwdArgs {
     uint32_t* n_contrib;
     uint8_t* qhit;  // per sorted instance: bit q set if some pixel of quadrant q blended it (pre-zeroed)
     int box_only;   // experiments / tests (G4S_BOX_ONLY): skip quadrants by the bounding box only
+    int no_fastpath;  // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
     float* out_color;
     float* out_others;
 };
@@ -187,6 +188,7 @@ struct BlendBwdArgs {
     const float* dL_depths;
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
     uint8_t* rec_flag; // R bytes, pre-cleared: bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
+    int no_fastpath;   // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
     int dbg;           // experiments only (G4S_BWD_DBG): 1 skip reduction, 2 skip gradient math, 4 skip evaluation
 };
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);

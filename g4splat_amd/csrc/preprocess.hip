@@ -172,6 +172,28 @@ __device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, 
     out[7] = 1.0f;
 }
 
+// REC_NO_LOWPASS: true if the low-pass exponent rho2d can never be the smaller one where it matters -- at every
+// integer pixel whose rho2d could still pass the alpha test (a disk of <= 2.4 px around the centre, <= 25 pixels)
+// the 3-D exponent is smaller and outside the tie band -- evaluated with the blend loops' own arithmetic
+// (eval_rho), so that eval_pair(nolp = true) is bit-identical to eval_pair(nolp = false) for this splat (g4s_device.h).
+__device__ __forceinline__ bool lowpass_never_matters(const float* T, float cx, float cy, float opa) {
+    const float thr = 2.0f * logf(255.0f * opa);
+    if (!(thr > 0.0f) || !(fabsf(cx) < 1e7f) || !(fabsf(cy) < 1e7f)) return false;
+    const float tt = thr * 1.01f + 0.1f;
+    const float r = sqrtf(0.5f * tt) + 0.01f;
+    for (int yy = (int)ceilf(cy - r); yy <= (int)floorf(cy + r); yy++)
+        for (int xx = (int)ceilf(cx - r); xx <= (int)floorf(cx + r); xx++) {
+            const float ddx = cx - (float)xx, ddy = cy - (float)yy;
+            if (FILTER_INV_SQUARE * fmaf(ddx, ddx, ddy * ddy) > tt) continue;  // eval_rho's rho2d, before the costly part
+            PairEval e;
+            bool tie;
+            if (!eval_rho((float)xx, (float)yy, cx, cy, T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], e, tie)) continue;
+            if (e.rho2d > tt) continue;
+            if (tie || !(e.rho3d <= e.rho2d)) return false;
+        }
+    return true;
+}
+
 // Loads the 3*(deg+1)^2 active SH floats of Gaussian idx into registers.  vec16: the records are
 // 192 B ([16][3] floats) on a 16-byte aligned base, so they are fetched as 16-byte quads.
 __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int deg, bool vec16,
@@ -301,7 +323,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         touched = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
                         rec[0] = cx;
                         rec[1] = cy;
-                        rec[3] = __uint_as_float(touched);
+                        rec[3] = __uint_as_float(touched | (lowpass_never_matters(T, cx, cy, opa) ? REC_NO_LOWPASS : 0u));
                         rec[4] = normal.x;
                         rec[5] = normal.y;
                         rec[6] = normal.z;
@@ -511,7 +533,7 @@ __global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) 
         if (visible) {
             const float4 q0 = rq[0];
             off = __float_as_uint(q0.z);
-            cnt = __float_as_uint(q0.w);
+            cnt = __float_as_uint(q0.w) & ~REC_NO_LOWPASS;
         }
         s_off[t] = off;
         s_cnt[t] = cnt;

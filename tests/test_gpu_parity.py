@@ -338,11 +338,14 @@ def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
             assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, (tag, name)
 
 
-def test_quadrant_culling_never_changes_a_result(hip_lib):
-    """The exact cutoff-ellipse test of the forward only skips quadrants no pixel of which can pass the alpha test:
-    with it switched off (G4S_BOX_ONLY: bounding box only) every output, the blend state and the per-quadrant
-    contribution masks must be bit-identical -- on random small scenes (thin, huge, tiny, translucent splats, wide
-    fields of view) and at the metric's size."""
+@pytest.mark.parametrize("switch", ["G4S_BOX_ONLY", "G4S_NO_FASTPATH"])
+def test_shortcuts_never_change_a_result(hip_lib, switch):
+    """Two shortcuts of the blend kernels are pure work-savers and can be switched off from the environment:
+      G4S_BOX_ONLY     the forward skips quadrants by the bounding box only, not by the exact cutoff ellipse;
+      G4S_NO_FASTPATH  every splat takes the general per-pixel evaluation, also those whose record says that the
+                       low-pass exponent can never matter (REC_NO_LOWPASS).
+    With either one off every output, the blend state and all gradients must be bit-identical -- on random small
+    scenes (thin, huge, tiny, sub-pixel, translucent splats, wide fields of view) and at the metric's size."""
     import os
     import torch
     from g4splat_amd import synthetic
@@ -352,11 +355,11 @@ def test_quadrant_culling_never_changes_a_result(hip_lib):
         g = cotangents(inp["H"], inp["W"], seed=7)
         for box_only in (False, True):
             if box_only:
-                os.environ["G4S_BOX_ONLY"] = "1"
+                os.environ[switch] = "1"
             try:
                 h = run_hip(inp, g)  # the gradients depend on the contribution masks the forward records
             finally:
-                os.environ.pop("G4S_BOX_ONLY", None)
+                os.environ.pop(switch, None)
             st = hip_state(h, inp)
             outs.append([h["color"], h["others"], st["final_T"].copy(), st["n_contrib"].copy()] +
                         [h["grads"][k] for k in sorted(h["grads"])])
@@ -366,7 +369,7 @@ def test_quadrant_culling_never_changes_a_result(hip_lib):
         rng = np.random.default_rng(500 + seed)
         inp = scene_inputs(P=int(rng.choice([50, 1500, 6000])), W=int(rng.choice([64, 177, 320])),
                            H=int(rng.choice([48, 130, 200])), seed=500 + seed, D=int(rng.integers(0, 4)),
-                           scale_mul=float(rng.choice([0.2, 1.0, 3.0, 12.0])), opacity_max=float(rng.choice([0.05, 0.5, 1.0])),
+                           scale_mul=float(rng.choice([0.02, 0.2, 1.0, 3.0, 12.0])), opacity_max=float(rng.choice([0.05, 0.5, 1.0])),
                            fov_deg=float(rng.uniform(30, 115)))
         if seed % 3 == 0:  # needle-like splats: their cutoff conic is nearly degenerate
             inp["scales"] = (inp["scales"] * np.array([[8.0, 0.1]], np.float32)).astype(np.float32)
