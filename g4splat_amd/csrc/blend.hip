@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
     BwdPixel p[4];
-    uint32_t max_last = 0;
+    uint32_t max_last = 0, max_median = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         x.nTfbg = -T_final * ((bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2);
         x.T = T_final;
         max_last = max(max_last, x.last_c);  // pixels outside the image keep last_c = 0: never active
+        max_median = max(max_median, x.median_c);
     }
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m = mscale - dmd_k / depth, dm/ddepth = dmd_k / depth^2
@@ -301,6 +302,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 
     // list positions >= the tile's max last_contributor cannot contribute anywhere
     const int n_live = (int)wave_max_u32(max_last);
+    // 1-based list position of the deepest median contributor of the tile: entries behind it skip the median term
+    const uint32_t tile_max_median = wave_max_u32(max_median);
     // (records of instances that receive no contribution are never written; rec_flag tells the fold which are)
 
     // batches from the back of the live range; lane t stages list position hi-1-t
@@ -379,7 +382,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     const float inv_cd = fast_rcp(c_d);
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
-                    float dL_dz = (pos + 1 == x.median_c) ? x.dL_dmedian : 0.0f;
+                    float dL_dz = 0.0f;
+                    if (pos < tile_max_median) dL_dz = (pos + 1 == x.median_c) ? x.dL_dmedian : 0.0f;  // scalar branch
                     const float dL_dweight = fmaf(m_d, fmaf(m_d, x.A2, -x.D2), x.C2);
                     const float dwt = dL_dweight - x.last_dL_dT;
                     dL_dalpha += dwt;

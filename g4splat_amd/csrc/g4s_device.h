@@ -275,7 +275,8 @@ __device__ __forceinline__ bool eval_rho(float pxf, float pyf, float cx, float c
 // low-pass exponent rho2d could still pass the alpha test the 3-D exponent is the smaller one and is not in the tie
 // band -- so rho = rho3d, and the low-pass arithmetic (rho2d, the tie test, two selects: 11 instructions of the ~46)
 // is skipped with bit-identical results.  (Where rho2d is too large to pass, min(rho3d, rho2d) fails the alpha test
-// whichever of the two is used.)  The general extras sit inside one uniform branch that only refines values the
+// whichever of the two is used.)  The flag also certifies that the interpolated depth stays above the near plane
+// wherever alpha can pass (depth is affine in s and |s|^2 <= t there), which makes that test redundant too.  The general extras sit inside one uniform branch that only refines values the
 // common code has already produced, so the two kinds of splat share everything else without register shuffling.
 __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float cx, float cy, float Tux, float Tuy,
                                           float Tuz, float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz,
@@ -299,6 +300,7 @@ __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
     e.in3d = true;
     float rho = e.rho3d;
+    e.depth = fmaf(e.sx, Twx, e.sy * Twy) + Twz;
     if (!nolp) {
         e.dx = cx - pxf;
         e.dy = cy - pyf;
@@ -307,14 +309,16 @@ __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float
             e.sx = ppx / ppz;
             e.sy = ppy / ppz;
             e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
+            e.depth = fmaf(e.sx, Twx, e.sy * Twy) + Twz;
         }
         // rho = min(rho3d, rho2d) and the depth select share one compare.  (NaN rho3d -- 0 * inf when p.z is
         // denormal -- takes the rho2d side in both, like fminf.)
         e.in3d = e.rho3d <= e.rho2d;
         rho = e.in3d ? e.rho3d : e.rho2d;
+        e.depth = e.in3d ? e.depth : Twz;
+        // (REC_NO_LOWPASS also certifies depth >= near wherever the splat can pass the alpha test)
+        if (e.depth < NEAR_N) return false;
     }
-    e.depth = e.in3d ? fmaf(e.sx, Twx, e.sy * Twy) + Twz : Twz;
-    if (e.depth < NEAR_N) return false;
     // forward.cu:383-385 `power = -0.5 rho; if (power > 0) continue;` can never fire (rho is a sum of squares),
     // and exp(power) = exp2(rho * (-0.5 log2 e)): scaling by -0.5 is exact, so folding it into the constant
     // rounds exactly like (-0.5f * rho) * log2e.  One v_exp_f32: rho in [0, 11.2] for anything that can pass,

@@ -172,7 +172,8 @@ __device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, 
     out[7] = 1.0f;
 }
 
-// REC_NO_LOWPASS: true if the low-pass exponent rho2d can never be the smaller one where it matters -- at every
+// REC_NO_LOWPASS: true if (a) the interpolated depth cannot fall below the near plane where the splat passes the alpha
+// test and (b) the low-pass exponent rho2d can never be the smaller one where it matters -- at every
 // integer pixel whose rho2d could still pass the alpha test (a disk of <= 2.4 px around the centre, <= 25 pixels)
 // the 3-D exponent is smaller and outside the tie band -- evaluated with the blend loops' own arithmetic
 // (eval_rho), so that eval_pair(nolp = true) is bit-identical to eval_pair(nolp = false) for this splat (g4s_device.h).
@@ -180,6 +181,8 @@ __device__ __forceinline__ bool lowpass_never_matters(const float* T, float cx, 
     const float thr = 2.0f * logf(255.0f * opa);
     if (!(thr > 0.0f) || !(fabsf(cx) < 1e7f) || !(fabsf(cy) < 1e7f)) return false;
     const float tt = thr * 1.01f + 0.1f;
+    // depth = s.x Tw.x + s.y Tw.y + Tw.z with |s|^2 <= t wherever alpha passes: never below the near plane?
+    if (!(T[8] - sqrtf(tt) * sqrtf(T[6] * T[6] + T[7] * T[7]) > NEAR_N * 1.05f)) return false;
     const float r = sqrtf(0.5f * tt) + 0.01f;
     for (int yy = (int)ceilf(cy - r); yy <= (int)floorf(cy + r); yy++)
         for (int xx = (int)ceilf(cx - r); xx <= (int)floorf(cx + r); xx++) {
