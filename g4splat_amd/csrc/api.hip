@@ -157,7 +157,7 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     const int passes = (tile_bits + 7) / 8;
     out->rec = g.rec;
     out->clamped = g.clamped;
-    out->depth_sorted = g.vals_a;  // four passes -> back in the first buffer
+    out->depth_sorted = g.vals_b;  // packed into the *_b arrays, four passes -> back in the first buffer
     out->tiles_touched = g.tiles_touched;
     out->geom_bytes = g.bytes;
     out->entries = (passes & 1) ? b.ent_b : b.ent_a;
@@ -240,40 +240,55 @@ extern "C" int g4s_rasterizer_forward(
         pa.scale_modifier = scale_modifier;
         pa.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16));
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
-        pa.depth_keys = keys_a; pa.gidx = vals_a;
+        pa.depth_keys = keys_a;
         pa.ref_block_sums = (uint32_t*)(geom + GL.ref_block_sums);
         pa.idx_block_sums = (uint32_t*)(geom + GL.idx_block_sums);
+        pa.vis_block_sums = (uint32_t*)(geom + GL.vis_block_sums);
         { ProfScope ps(PF_PREPROCESS_FWD, stream); launch_preprocess_fwd(pa, stream); }
         CHECK_LAUNCH("preprocess_fwd");
 
-        // depth order of the Gaussians (stable => ties by ascending index)
-        int cur;
-        { ProfScope ps(PF_DEPTH_SORT, stream);
-          cur = radix_sort_u32_pairs(keys_a, keys_b, vals_a, vals_b, P, (uint32_t*)(geom + GL.hist),
-                                     (uint32_t*)(geom + GL.bin_total), stream); }
-        CHECK_LAUNCH("depth sort");
-        const uint32_t* gidx_sorted = cur ? vals_b : vals_a;
-
+        // Everything the host has to know comes out of the preprocess' per-block partial sums: the one host
+        // synchronisation of the forward (rasterizer_impl.cu:281-282) sits right behind it, and every later launch
+        // is sized for the Gaussians that actually emit instances.
+        uint32_t* idx_block_offs = (uint32_t*)(geom + GL.idx_block_offs);
+        uint32_t* vis_block_offs = (uint32_t*)(geom + GL.vis_block_offs);
         { ProfScope ps(PF_COUNT_SCAN, stream);
-          launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs,
-                            (const uint32_t*)(geom + GL.ref_block_sums), d_total, GL.nblocks, stream); }
-        CHECK_LAUNCH("count scan");
-
-        launch_grad_slots(P, tiles_touched, (const uint32_t*)(geom + GL.idx_block_sums),
-                          (uint32_t*)(geom + GL.idx_block_offs), d_total + 2, rec, GL.nblocks, stream);
-        CHECK_LAUNCH("grad slots");
-
-        // the one host synchronisation of the forward (rasterizer_impl.cu:281-282)
+          launch_scan_totals(pa.idx_block_sums, idx_block_offs, pa.ref_block_sums, pa.vis_block_sums, vis_block_offs,
+                             d_total, GL.nblocks, stream); }
+        CHECK_LAUNCH("scan totals");
         uint32_t* h_total = pinned_word();
         if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
-        HIP_TRY(hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_total, d_total, 12, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         // h_total[0]: instances actually binned (3-sigma rect intersected with the alpha-cutoff box),
-        // h_total[1]: the reference's count (3-sigma rect only) = the num_rendered this call returns.
+        // h_total[1]: the reference's count (3-sigma rect only) = the num_rendered this call returns,
+        // h_total[2]: Gaussians that emit at least one instance.
         // All buffers are laid out for the reference count, which bounds the binned one.
         if (h_total[1] > 0x7FFFFFFFu) return fail(G4S_ERR_INVALID_ARGUMENT, "num_rendered overflows int");
         R = (int)h_total[1];
         const int R_binned = (int)h_total[0];
+        const int V_emit = (int)h_total[2];
+
+        launch_grad_slots(P, tiles_touched, idx_block_offs, rec, GL.nblocks, stream);
+        CHECK_LAUNCH("grad slots");
+
+        // depth order of the emitting Gaussians (stable => ties by ascending index): pack, then sort
+        const uint32_t* gidx_sorted = vals_b;
+        if (V_emit > 0) {
+            ProfScope ps(PF_DEPTH_SORT, stream);
+            launch_compact_keys(P, tiles_touched, keys_a, vis_block_offs, keys_b, vals_b, GL.nblocks, stream);
+            const int cur = radix_sort_u32_pairs(keys_b, keys_a, vals_b, vals_a, V_emit, (uint32_t*)(geom + GL.hist),
+                                                 (uint32_t*)(geom + GL.bin_total), stream);
+            gidx_sorted = cur ? vals_a : vals_b;
+        }
+        CHECK_LAUNCH("depth sort");
+        const int nblocks_v = (V_emit + 255) / 256;
+        if (V_emit > 0) {
+            ProfScope ps(PF_COUNT_SCAN, stream);
+            launch_count_scan(V_emit, gidx_sorted, tiles_touched, block_sums, block_offs, block_sums, d_total + 4,
+                              nblocks_v, stream);
+        }
+        CHECK_LAUNCH("count scan");
 
         const BinLayout BL = bin_layout((size_t)R);
         char* bin = binning_buffer(binning_ctx, BL.bytes);
@@ -286,7 +301,7 @@ extern "C" int g4s_rasterizer_forward(
         if (R_binned > 0) {
             HIP_TRY(hipMemsetAsync(qhit_ptr, 0, align_up((size_t)R_binned, 256), stream));  // whole 256-B granules: a ragged byte count takes a slow fill path
             { ProfScope ps(PF_EMIT, stream);
-              launch_emit(P, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, GL.nblocks,
+              launch_emit(V_emit, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, nblocks_v,
                           stream); }
             CHECK_LAUNCH("emit");
             const int tile_bits = (int)higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:301

@@ -291,11 +291,42 @@ __global__ void __launch_bounds__(256) grad_slots_kernel(int P, const uint32_t* 
     const uint32_t local = block256_excl_scan_u32(c, sm4, &total);
     if (c > 0) rec[(size_t)idx * REC_FLOATS + 2] = __uint_as_float(idx_block_offs[blockIdx.x] + local);
 }
-void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_sums, uint32_t* idx_block_offs,
-                       uint32_t* scratch_total, float* rec, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
-                       idx_block_sums, scratch_total);
+void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec, int nblocks,
+                       hipStream_t s) {
     hipLaunchKernelGGL(grad_slots_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_touched, idx_block_offs, rec);
+}
+
+void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
+                        const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
+                       ref_block_sums, total);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, vis_block_sums, vis_block_offs,
+                       vis_block_sums, total + 2);
+}
+
+// Only Gaussians that emit instances take part in the depth sort and in everything after it (typically a
+// quarter of the scene): their (depth key, index) pairs are packed in index order, so the stable sort still
+// resolves equal depths by ascending index.
+__global__ void __launch_bounds__(256) compact_keys_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                           const uint32_t* __restrict__ depth_keys,
+                                                           const uint32_t* __restrict__ vis_block_offs,
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
+    __shared__ uint32_t sm4[4];
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    const bool emits = idx < P && tiles_touched[idx] > 0;
+    uint32_t total;
+    const uint32_t local = block256_excl_scan_u32(emits ? 1u : 0u, sm4, &total);
+    if (emits) {
+        const uint32_t dst = vis_block_offs[blockIdx.x] + local;
+        keys_out[dst] = depth_keys[idx];
+        idx_out[dst] = (uint32_t)idx;
+    }
+}
+void launch_compact_keys(int P, const uint32_t* tiles_touched, const uint32_t* depth_keys, const uint32_t* vis_block_offs,
+                         uint32_t* keys_out, uint32_t* idx_out, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(compact_keys_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_touched, depth_keys, vis_block_offs,
+                       keys_out, idx_out);
 }
 
 void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,

@@ -50,7 +50,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // (the reference's GeometryState/BinningState/ImageState, rasterizer_impl.h:21-73).
 struct GeomLayout {
     size_t rec, clamped, tiles_touched, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
-        block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, total, bytes;
+        block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, vis_block_sums, vis_block_offs, total, bytes;
     int nchunks;   // radix chunks over P
     int nblocks;   // 256-wide blocks over P
 };
@@ -76,13 +76,16 @@ inline GeomLayout geom_layout(size_t P) {
     L.keys_b = take(P * 4);
     L.vals_a = take(P * 4);
     L.vals_b = take(P * 4);
-    L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
+    // the depth sort runs over the emitting Gaussians only (n <= P): capacity for the finest chunking of any n <= P
+    L.hist = take((size_t)256 * (size_t)((P + 255) / 256 < 2112 ? (P + 255) / 256 + 1 : 2112) * 4);
     L.bin_total = take(256 * 4);
     L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.ref_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.idx_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.idx_block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.vis_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.vis_block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.total = take(256);
     L.bytes = o + 256;  // slack for aligning the chunk base
     return L;
@@ -119,6 +122,7 @@ struct PreprocessArgs {
     int P, D, M, W, H, tiles_x, tiles_y;
     uint32_t* ref_block_sums;  // per 256-Gaussian block: sum of the reference's tiles_touched (3-sigma rect)
     uint32_t* idx_block_sums;  // per 256-Gaussian block (index order): sum of the binned tile counts
+    uint32_t* vis_block_sums;  // per 256-Gaussian block: number of Gaussians that emit at least one instance
     const float *means3D, *scales, *rotations, *opacities, *shs, *transMat_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;
@@ -128,7 +132,6 @@ struct PreprocessArgs {
     uint32_t* tiles_touched;
     int* radii;
     uint32_t* depth_keys;
-    uint32_t* gidx;
 };
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
@@ -148,8 +151,17 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
                        hipStream_t s);
 // Gradient-record slots in INDEX order: rec[idx].inst_off = exclusive scan of tiles_touched over idx
 // (so that the per-Gaussian fold of the backward streams the record buffer sequentially).
-void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_sums, uint32_t* idx_block_offs,
-                       uint32_t* scratch_total, float* rec, int nblocks, hipStream_t s);
+void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec, int nblocks,
+                       hipStream_t s);
+// Totals and block offsets that only need the preprocess' per-block partial sums (no sort): exclusive scans of
+// idx_block_sums and vis_block_sums; total[0] = instances binned, total[1] = the reference's num_rendered,
+// total[2] = number of emitting Gaussians.
+void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
+                        const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
+                        hipStream_t s);
+// Stable compaction (index order) of the emitting Gaussians' (depth key, index) pairs.
+void launch_compact_keys(int P, const uint32_t* tiles_touched, const uint32_t* depth_keys, const uint32_t* vis_block_offs,
+                         uint32_t* keys_out, uint32_t* idx_out, int nblocks, hipStream_t s);
 void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,
                  const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
                  hipStream_t s);

@@ -354,22 +354,25 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
         a.tiles_touched[idx] = touched;
         a.radii[idx] = radius_out;
         a.depth_keys[idx] = key;
-        a.gidx[idx] = (uint32_t)idx;
     }
     // num_rendered of the reference = sum of its tiles_touched: per-block partial, summed by the
     // count-scan kernel (a same-address atomic per wave serialises at ~90 atomics/us on this part)
-    __shared__ uint32_t s_ref[4], s_tight[4];
+    __shared__ uint32_t s_ref[4], s_tight[4], s_vis[4];
     const uint32_t wsum = wave_sum_u32(touched_ref);
     const uint32_t tsum = wave_sum_u32(touched);
+    const uint32_t vsum = (uint32_t)__popcll(__ballot(touched > 0));
     if (lane_id() == 0) {
         s_ref[threadIdx.x >> 6] = wsum;
         s_tight[threadIdx.x >> 6] = tsum;
+        s_vis[threadIdx.x >> 6] = vsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         a.ref_block_sums[blockIdx.x] = (s_ref[0] + s_ref[1]) + (s_ref[2] + s_ref[3]);
         // binned-instance count of this block in INDEX order: base of the gradient-record slots
         a.idx_block_sums[blockIdx.x] = (s_tight[0] + s_tight[1]) + (s_tight[2] + s_tight[3]);
+        // Gaussians of this block that emit instances: base of their slots in the compacted depth-sort input
+        a.vis_block_sums[blockIdx.x] = (s_vis[0] + s_vis[1]) + (s_vis[2] + s_vis[3]);
     }
 }
 

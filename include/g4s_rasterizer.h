@@ -142,7 +142,7 @@ typedef struct g4s_layout {
     /* geometry chunk */
     size_t rec;          /* P x 32 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb, box, cutoff ellipse */
     size_t clamped;      /* P x u8 (bit c = channel c clamped) */
-    size_t depth_sorted; /* P x u32 Gaussian indices in (depth, index) order, culled ones last */
+    size_t depth_sorted; /* u32 indices of the Gaussians that emit instances, in (depth, index) order */
     size_t tiles_touched;/* P x u32 */
     size_t geom_bytes;
     /* binning chunk */
