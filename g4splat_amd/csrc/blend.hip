@@ -3,12 +3,12 @@
 // Reference semantics: dsr/cuda_rasterizer/forward.cu:258-443, backward.cu:143-440.
 //
 // MI355X design:
-//   * a tile's sorted instance list is staged through LDS as 96-byte splat records (six 16-byte
-//     quads per entry, SoA in LDS so the inner loop reads them with conflict-free broadcast
-//     ds_read_b128);
-//   * pixels are grouped in wave64-sized 8x8 quadrants.  Before any per-pixel arithmetic a
-//     quadrant is tested against the splat's alpha-cutoff box (record quad 5) with wave-uniform
-//     compares, and every expensive stage sits behind a wave-uniform __any();
+//   * a tile's sorted instance list is staged through LDS: the five 16-byte quads of the splat record that the
+//     per-pixel arithmetic needs, SoA in LDS so the inner loop reads them with conflict-free broadcast
+//     ds_read_b128 (the three culling quads are consumed by the staging thread itself);
+//   * pixels are grouped in wave64-sized 8x8 quadrants; which quadrants a splat can reach at all (its
+//     alpha-cutoff region: bounding box, then exact ellipse + low-pass disk) is decided once per staged
+//     entry, and the quadrant waves visit only those entries;
 //   * forward: 4 waves per tile, one quadrant each; a saturated pixel carries Tt = 0, a quadrant stops as
 //     soon as its 64 pixels are saturated; per instance the forward records which quadrants blended it
 //     (qhit, one byte);
