@@ -331,7 +331,6 @@ extern "C" int g4s_rasterizer_forward(
     ba.qhit = qhit_ptr;
     ba.box_only = getenv("G4S_BOX_ONLY") != nullptr;
     ba.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
-    if (getenv("G4S_SKIP_BLEND")) return R;  // bring-up aid: leave the binning state for inspection
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");
     return R;
@@ -400,7 +399,6 @@ extern "C" int g4s_rasterizer_backward(
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
         bb.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
-        bb.dbg = getenv("G4S_BWD_DBG") ? atoi(getenv("G4S_BWD_DBG")) : 0;
         { ProfScope ps(PF_BLEND_BWD, stream); launch_blend_bwd(bb, stream); }
         CHECK_LAUNCH("blend_bwd");
     }
@@ -418,7 +416,6 @@ extern "C" int g4s_rasterizer_backward(
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
     pb.gsum = gsum; pb.rec_flag = rec_flag;
     pb.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
-    pb.dbg_skip = getenv("G4S_K8_SKIP") ? atoi(getenv("G4S_K8_SKIP")) : 0;
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dtransMat = dL_dtransMat; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
     pb.dL_drot = dL_drot;

@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             // low-pass centre terms -- those are non-zero only when some pixel took the 2-D filter branch
             // (rare for splats wider than a pixel), so their group is reduced and stored only then.  The record
             // buffer is not cleared: rec_flag[slot] (pre-cleared, one byte) says which parts are valid.
-            if (!(a.dbg & 1)) {
+            {
                 const uint32_t slot = s_slot[j];
                 float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
                 float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],

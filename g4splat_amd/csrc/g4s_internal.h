@@ -201,7 +201,6 @@ struct BlendBwdArgs {
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
     uint8_t* rec_flag; // R bytes, pre-cleared: bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
     int no_fastpath;   // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
-    int dbg;           // experiments only (G4S_BWD_DBG): 1 skip reduction, 2 skip gradient math, 4 skip evaluation
 };
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 
@@ -216,7 +215,6 @@ struct PreprocessBwdArgs {
     const uint8_t* rec_flag;
     float* gsum;  // P x 18 folded gradient terms (workspace)
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
-    int dbg_skip;   // bring-up/experiments only (G4S_K8_SKIP): 1 = skip fold, 2 = skip SH, 4 = skip small outputs
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
         *dL_drot;
 };

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) 
     // and a float2 per record for terms 16..17; the partial sums are combined with DPP row rotates
     // and two cross-row exchanges in a fixed order.  A Gaussian with hundreds of instances costs
     // cnt/16 steps of one wave instead of serialising a single thread.
-    if (!(a.dbg_skip & 1)) {
+    {
         const int lane = lane_id();
         const int wbase = (t >> 6) * 64;  // first local Gaussian of this wave
         const uint32_t my_cnt = s_cnt[t], my_off = s_off[t];
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             dmean3[1] = dL_dM[2][1];
             dmean3[2] = dL_dM[2][2];
         }
-        if (a.shs != nullptr && !(a.dbg_skip & 2)) {
+        if (a.shs != nullptr) {
             float sh[48];
             load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
             const F3 dm = sh_backward(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
@@ -807,7 +807,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     // rows of dL_dsh that belong to invisible Gaussians were zero-filled by the caller (one
     // hipMemsetAsync at copy-engine speed instead of 192-byte strided stores from here)
 
-    if (a.dbg_skip & 4) return;
     a.dL_dmean2D[3 * idx] = dmean2[0]; a.dL_dmean2D[3 * idx + 1] = dmean2[1]; a.dL_dmean2D[3 * idx + 2] = dmean2[2];
     if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5]; }
     a.dL_dopacity[idx] = g[17];
