@@ -5,6 +5,7 @@ Same signature, same camera / model attributes read, same returned dict keys and
     render, viewspace_points, visibility_filter, radii                      (:110-114)
     rend_alpha, rend_normal, rend_normal_cam, rend_dist, surf_depth,
     surf_normal, surf_normal_cam, rend_depth                                (:155-164)
+`render_gslist` (:169-363) renders several models as one scene.
 The rasterizer call goes to the HIP library through the drop-in `GaussianRasterizer`; the map
 post-processing (:117-164 + utils/point_utils.py:9-37) is one fused HIP
 kernel each way (`render_maps`).
@@ -62,4 +63,45 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             "radii": radii}
 
     rets.update((maps_fn or render_maps)(allmap, viewpoint_camera, pipe.depth_ratio))
+    return rets
+
+
+class _JoinedModels:
+    """The attributes `render()` reads, for a list of models rendered as one scene (render_gslist, :169-216: every
+    activated tensor is concatenated in list order; the SH degree is the first model's)."""
+
+    def __init__(self, pc_list):
+        self._pcs = pc_list
+        self.active_sh_degree = pc_list[0].active_sh_degree
+
+    def _cat(self, name):
+        return torch.cat([getattr(pc, name) for pc in self._pcs], dim=0)
+
+    get_xyz = property(lambda self: self._cat("get_xyz"))
+    get_opacity = property(lambda self: self._cat("get_opacity"))
+    get_scaling = property(lambda self: self._cat("get_scaling"))
+    get_rotation = property(lambda self: self._cat("get_rotation"))
+    get_features = property(lambda self: self._cat("get_features"))
+
+    def get_covariance(self, scaling_modifier=1):
+        return torch.cat([pc.get_covariance(scaling_modifier) for pc in self._pcs], dim=0)
+
+
+def render_gslist(viewpoint_camera, pc_list, pipe, bg_color, scaling_modifier=1.0, override_color=None, rasterizer_cls=None,
+                  maps_fn=None):
+    """2dgs/gaussian_renderer/__init__.py:169-363: the models of `pc_list` rendered together.  `override_color` may be
+    a list with one tensor per model (:286-287).  Returns render()'s dictionary without the two `_cam` normal maps
+    plus `model_start_indices` = [0, P_0, P_0 + P_1, ...] (:355-361)."""
+    if not isinstance(pc_list, list):
+        raise ValueError("pc_list must be a list of GaussianModel objects")
+    if isinstance(override_color, list):
+        override_color = torch.cat(override_color, dim=0)
+    rets = render(viewpoint_camera, _JoinedModels(pc_list), pipe, bg_color, scaling_modifier, override_color,
+                  rasterizer_cls=rasterizer_cls, maps_fn=maps_fn)
+    rets.pop("rend_normal_cam", None)
+    rets.pop("surf_normal_cam", None)
+    starts = [0]
+    for pc in pc_list:
+        starts.append(starts[-1] + int(pc.get_xyz.shape[0]))
+    rets["model_start_indices"] = starts
     return rets

@@ -8,7 +8,7 @@ import torch
 from cpu_rasterizer import OracleRasterizer
 from g4splat_amd import synthetic
 from g4splat_amd.gaussian_model import GaussianModel
-from g4splat_amd.gaussian_renderer import render
+from g4splat_amd.gaussian_renderer import render, render_gslist
 from oracle.render_maps_ref import depth_to_normal, render_maps as maps_ref
 
 KEYS = {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_normal_cam",
@@ -98,3 +98,28 @@ def test_depth_to_normal_of_a_plane():
     fwd = torch.linalg.inv(cam.world_view_transform.T)[:3, 2]
     assert torch.allclose(inner.reshape(-1, 3).abs() @ torch.ones(3), (fwd.abs() @ torch.ones(3)).expand(inner.numel() // 3), atol=1e-3)
     assert not n[0].any() and not n[:, 0].any()
+
+
+def test_render_gslist_equals_render_of_the_union():
+    """render_gslist (2dgs/gaussian_renderer/__init__.py:169-363): two models rendered together == one model holding
+    both sets; dictionary keys of the reference; gradients reach both models."""
+    cam = _camera()
+    a, b = _model(P=120, seed=5), _model(P=80, seed=6)
+    pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False)
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    out = render_gslist(cam, [a, b], pipe, bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    assert set(out) == (KEYS - {"rend_normal_cam", "surf_normal_cam"}) | {"model_start_indices"}
+    assert out["model_start_indices"] == [0, 120, 200]
+    both = _model(P=200, seed=0)
+    with torch.no_grad():
+        for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+            getattr(both, name).copy_(torch.cat([getattr(a, name), getattr(b, name)], dim=0))
+    ref = render(cam, both, pipe, bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    for k in ("render", "rend_alpha", "rend_normal", "surf_depth", "surf_normal", "rend_dist", "rend_depth", "radii"):
+        assert torch.equal(out[k], ref[k]), k
+    (out["render"].mean() + out["rend_dist"].mean()).backward()
+    assert a._xyz.grad is not None and b._xyz.grad is not None and b._features_rest.grad.abs().sum() > 0
+    assert out["viewspace_points"].grad.shape == (200, 3)
+    import pytest
+    with pytest.raises(ValueError):
+        render_gslist(cam, a, pipe, bg)
