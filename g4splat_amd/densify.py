@@ -73,6 +73,16 @@ class DensifyMixin:
                 return {name: new}
         raise KeyError(name)
 
+    def _prune_optimizer(self, mask):
+        """:510-525 (mask = rows to KEEP); returns the rebound parameters by group name."""
+        self._edit_rows(keep=mask)
+        return {g["name"]: g["params"][0] for g in self.optimizer.param_groups}
+
+    def cat_tensors_to_optimizer(self, tensors_dict):
+        """:543-560; returns the rebound parameters by group name."""
+        self._edit_rows(append=tensors_dict)
+        return {g["name"]: g["params"][0] for g in self.optimizer.param_groups}
+
     def reset_opacity(self):
         """:436-439: opacities above 0.01 are pulled down to 0.01 (through the activation's inverse)."""
         cur = self.get_opacity

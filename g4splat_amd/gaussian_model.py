@@ -16,6 +16,24 @@ def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
 
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear interpolation from lr_init (step 0) to lr_final (step max_steps), optionally eased in by a sine
+    ramp from lr_delay_mult over the first lr_delay_steps (2dgs/utils/general_utils.py:30-64; pinned by
+    tests/golden/lr_schedule.npz)."""
+    import math
+
+    def lr(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        ramp = 1.0
+        if lr_delay_steps > 0:
+            ramp = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return ramp * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+    return lr
+
+
 class GaussianModel(DensifyMixin):
     def __init__(self, sh_degree=3, use_mip_filter=False):
         self.active_sh_degree = 0
@@ -91,10 +109,23 @@ class GaussianModel(DensifyMixin):
         self._set(means, colors, torch.log(scales), quaternions)
 
     # ---- optimisation ------------------------------------------------------------------------------
-    def training_setup(self, position_lr=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
+    def training_setup(self, training_args=None, position_lr=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
                        rotation_lr=0.001, fused=None):
-        """gaussian_model.py:248-266.  `fused` (default: on for HIP tensors): one-kernel Adam (optim.FusedAdam)
-        instead of torch.optim.Adam's foreach passes; same groups, names, lr, eps and state layout."""
+        """gaussian_model.py:248-266.  `training_args`: the reference's OptimizationParams-like object
+        (position_lr_init/final/delay_mult/max_steps, feature_lr, opacity_lr, scaling_lr, rotation_lr, percent_dense);
+        without it the keyword defaults (= arguments/__init__.py) apply.  `fused` (default: on for HIP tensors):
+        one-kernel Adam (optim.FusedAdam) instead of torch.optim.Adam's foreach passes; same groups, names, lr, eps and
+        state layout."""
+        position_lr_final, delay_mult, max_steps = position_lr / 100.0, 0.01, 30000
+        if training_args is not None:
+            ta = training_args
+            position_lr, feature_lr, opacity_lr = ta.position_lr_init, ta.feature_lr, ta.opacity_lr
+            scaling_lr, rotation_lr = ta.scaling_lr, ta.rotation_lr
+            position_lr_final, delay_mult, max_steps = ta.position_lr_final, ta.position_lr_delay_mult, ta.position_lr_max_steps
+            self.percent_dense = ta.percent_dense
+        self.xyz_scheduler_args = get_expon_lr_func(lr_init=position_lr * self.spatial_lr_scale,
+                                                    lr_final=position_lr_final * self.spatial_lr_scale,
+                                                    lr_delay_mult=delay_mult, max_steps=max_steps)
         n, dev = self._xyz.shape[0], self._xyz.device
         self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
         self.denom = torch.zeros((n, 1), device=dev)
@@ -113,6 +144,59 @@ class GaussianModel(DensifyMixin):
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    def update_learning_rate(self, iteration):
+        """gaussian_model.py:268-274: the xyz group follows the exponential schedule; returns the new rate."""
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+                return group["lr"]
+
+    def capture(self):
+        """gaussian_model.py:65-79: the checkpoint tuple train_with_refine_depth.py:606-608 hands to torch.save."""
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args=None, **setup_kw):
+        """gaussian_model.py:81-97."""
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+         self._opacity, self.max_radii2D, accum, denom, opt_dict, self.spatial_lr_scale) = model_args
+        self.training_setup(training_args, **setup_kw)
+        self.xyz_gradient_accum, self.denom = accum, denom
+        self.optimizer.load_state_dict(opt_dict)
+
+    def freeze_params(self):
+        """gaussian_model.py:99-121: no parameter receives gradients any more."""
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def get_covariance(self, scaling_modifier=1):
+        """gaussian_model.py:29-36,193-194: the 4x4 splat-to-world transform per Gaussian (rows: the two scaled tangent
+        axes, the normal, the centre) that render()'s compute_cov3D_python path multiplies into world2pix."""
+        from .densify import build_rotation
+        s = self.get_scaling * scaling_modifier
+        R = build_rotation(self._rotation)
+        L = R * torch.cat([s, torch.ones_like(s)], dim=-1)[:, None, :3]  # R @ diag(sx, sy, 1)
+        trans = torch.zeros((self._xyz.shape[0], 4, 4), dtype=torch.float, device=self._xyz.device)
+        trans[:, :3, :3] = L.permute(0, 2, 1)
+        trans[:, 3, :3] = self.get_xyz
+        trans[:, 3, 3] = 1
+        return trans
+
+    def set_mip_filter(self, use_mip_filter):
+        self.use_mip_filter = bool(use_mip_filter)
+
+    def gs_scale_loss(self, max_scale_thresh=0.05):
+        """gaussian_model.py:653-657: squared excess of the larger axis over a threshold, summed."""
+        excess = torch.clamp(self.get_scaling.max(dim=1).values - max_scale_thresh, min=0.0)
+        return torch.sum(excess ** 2)
+
+    def construct_list_of_attributes(self):
+        """gaussian_model.py:276-291."""
+        from .ply_io import attribute_names
+        return attribute_names(self._features_rest.shape[1], self._scaling.shape[1], self._rotation.shape[1],
+                               self.use_mip_filter)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         """gaussian_model.py:649-651: accumulate the per-view norm of the screen-space gradient."""

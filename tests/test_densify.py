@@ -121,3 +121,61 @@ def test_compute_mip_filter():
     assert torch.allclose(f[0], torch.tensor(2.0 * k)) and torch.allclose(f[1], torch.tensor(4.0 * k))
     assert torch.allclose(f[4], torch.tensor(1.0 * k)) and torch.allclose(f[5], torch.tensor(1.1 * k))
     assert torch.allclose(f[2], f.max()) and torch.allclose(f[3], f.max())
+
+
+def test_schedule_checkpoint_and_helpers(tmp_path):
+    """update_learning_rate against the reference's get_expon_lr_func (golden), capture/restore round trip through
+    torch.save, get_covariance against its definition, freeze_params, gs_scale_loss, the reference-named optimiser
+    wrappers, training_setup from an OptimizationParams-like object."""
+    import os
+    from types import SimpleNamespace
+    from g4splat_amd.gaussian_model import get_expon_lr_func
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr_schedule.npz"))
+    for i in range(3):
+        lr0, lr1, dsteps, dmult, msteps = g[f"args_{i}"]
+        f = get_expon_lr_func(lr_init=lr0, lr_final=lr1, lr_delay_steps=int(dsteps), lr_delay_mult=dmult, max_steps=int(msteps))
+        np.testing.assert_allclose([f(int(s)) for s in g["steps"]], g[f"lr_{i}"], rtol=1e-12, atol=0)
+    m = _model(P=11)
+    ta = SimpleNamespace(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+                         position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
+                         rotation_lr=0.001, percent_dense=0.02)
+    m.spatial_lr_scale = 4.3
+    m.training_setup(ta, fused=False)
+    assert m.percent_dense == 0.02
+    assert [grp["name"] for grp in m.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    assert abs(m.update_learning_rate(7000) - float(g["lr_0"][list(g["steps"]).index(7000)])) < 1e-15
+    assert m.optimizer.param_groups[0]["lr"] == m.update_learning_rate(7000)
+    # checkpoint tuple
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    m.optimizer.step()
+    m.xyz_gradient_accum = torch.rand((11, 1))
+    m.denom = torch.ones((11, 1))
+    path = str(tmp_path / "chkpnt.pth")
+    torch.save((m.capture(), 123), path)
+    args, it = torch.load(path, weights_only=False)
+    n = GaussianModel(sh_degree=2)
+    n.restore(args, ta, fused=False)
+    assert it == 123 and n.active_sh_degree == m.active_sh_degree and n.spatial_lr_scale == 4.3
+    for a, b in zip(m.parameters(), n.parameters()):
+        assert torch.equal(a, b)
+    assert torch.equal(n.xyz_gradient_accum, m.xyz_gradient_accum)
+    sa, sb = m.optimizer.state[m._xyz], n.optimizer.state[n._xyz]
+    assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and float(sa["step"]) == float(sb["step"]) == 1
+    # splat-to-world transform
+    T = m.get_covariance(2.0)
+    R = build_rotation(m._rotation.detach())
+    s = m.get_scaling.detach() * 2.0
+    assert torch.allclose(T[:, 0, :3], R[:, :, 0] * s[:, :1], atol=1e-6) and torch.allclose(T[:, 1, :3], R[:, :, 1] * s[:, 1:2], atol=1e-6)
+    assert torch.allclose(T[:, 2, :3], R[:, :, 2], atol=1e-6) and torch.equal(T[:, 3, :3], m._xyz.detach()) and (T[:, 3, 3] == 1).all()
+    assert float(m.gs_scale_loss(0.05).detach()) == float(torch.clamp(m.get_scaling.detach().max(1).values - 0.05, min=0).pow(2).sum())
+    assert m.construct_list_of_attributes()[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    kept = m._prune_optimizer(torch.arange(11) % 2 == 0)
+    assert kept["xyz"] is m._xyz and m._xyz.shape[0] == 6
+    grown = m.cat_tensors_to_optimizer({"xyz": torch.zeros(2, 3), "f_dc": torch.zeros(2, 1, 3), "f_rest": torch.zeros(2, 8, 3),
+                                        "opacity": torch.zeros(2, 1), "scaling": torch.zeros(2, 2), "rotation": torch.ones(2, 4)})
+    assert grown["rotation"] is m._rotation and m._rotation.shape[0] == 8
+    m.freeze_params()
+    assert not any(p.requires_grad for p in m.parameters())
+    m.set_mip_filter(True)
+    assert m.use_mip_filter
