@@ -1,7 +1,7 @@
 """Image metrics / photometric losses used around the render path (PSNR is part of the headline
 metric, L1 + SSIM form the reference's photometric loss).  Pure torch, device agnostic; pinned to the
-reference's implementations (2dgs/utils/loss_utils.py:17-79, 2dgs/utils/image_utils.py:19-21) by
-tests/golden/losses.npz."""
+reference's implementations (2dgs/utils/loss_utils.py:17-79, 2dgs/utils/image_utils.py:15-21) by
+tests/golden/losses.npz and losses_misc.npz.  The training step's hot loss is the fused HIP one (losses.py)."""
 import math
 
 import torch
@@ -10,6 +10,28 @@ import torch.nn.functional as F
 
 def l1_loss(network_output, gt):
     return torch.abs(network_output - gt).mean()
+
+
+def l1_loss_with_conf(network_output, gt, conf):
+    """loss_utils.py:20-24: confidence-weighted L1, normalised by the confidence mass."""
+    return (torch.abs(network_output - gt) * conf).sum() / (conf.sum() + 1e-8)
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def smooth_loss(disp, img):
+    """loss_utils.py:36-44: edge-aware second-order smoothness of a disparity map."""
+    gdx = torch.abs(disp[:, 1:-1, :-2] + disp[:, 1:-1, 2:] - 2 * disp[:, 1:-1, 1:-1])
+    gdy = torch.abs(disp[:, :-2, 1:-1] + disp[:, 2:, 1:-1] - 2 * disp[:, 1:-1, 1:-1])
+    gix = torch.mean(torch.abs(img[:, 1:-1, :-2] - img[:, 1:-1, 2:]), 0, keepdim=True) * 0.5
+    giy = torch.mean(torch.abs(img[:, :-2, 1:-1] - img[:, 2:, 1:-1]), 0, keepdim=True) * 0.5
+    return (gdx * torch.exp(-gix)).mean() + (gdy * torch.exp(-giy)).mean()
+
+
+def mse(img1, img2):
+    return ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
 
 
 def psnr(img1, img2):

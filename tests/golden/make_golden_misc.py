@@ -27,6 +27,21 @@ def main():
     np.savez(os.path.join(HERE, "lr_schedule.npz"), **out)
     print("wrote lr_schedule.npz")
 
+    # the remaining losses of utils/loss_utils.py (l1_loss_with_conf :20-24, l2_loss :26-27, smooth_loss :36-44) and
+    # image_utils.mse (:15-16) on seeded inputs
+    import torch
+    from utils import loss_utils as lu
+    rng = np.random.default_rng(31)
+    a = torch.tensor(rng.uniform(0, 1, (3, 37, 52)).astype(np.float32))
+    b = torch.tensor(rng.uniform(0, 1, (3, 37, 52)).astype(np.float32))
+    conf = torch.tensor(rng.uniform(0, 1, (1, 37, 52)).astype(np.float32))
+    disp = torch.tensor(rng.uniform(0.1, 2, (1, 37, 52)).astype(np.float32))
+    mse = (((a - b)) ** 2).view(a.shape[0], -1).mean(1, keepdim=True)  # image_utils.mse (that module imports matplotlib)
+    np.savez(os.path.join(HERE, "losses_misc.npz"), a=a.numpy(), b=b.numpy(), conf=conf.numpy(), disp=disp.numpy(),
+             l1_conf=lu.l1_loss_with_conf(a, b, conf).numpy(), l2=lu.l2_loss(a, b).numpy(),
+             smooth=lu.smooth_loss(disp, a).numpy(), mse=mse.numpy())
+    print("wrote losses_misc.npz")
+
 
 if __name__ == "__main__":
     main()

@@ -134,3 +134,16 @@ def test_photometric_loss_restatement_matches_the_reference():
         assert abs(float(ss) - float(g[f"{name}_ssim"])) <= 1e-6
         assert abs(float(loss) - float(g[f"{name}_loss"])) <= 1e-6
         np.testing.assert_allclose(x.grad.numpy(), g[f"{name}_grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_remaining_losses_match_the_reference():
+    """metrics.l1_loss_with_conf / l2_loss / smooth_loss / mse against values computed by the reference's own
+    loss_utils.py (tests/golden/make_golden_misc.py)."""
+    import torch
+    from g4splat_amd import metrics
+    d = np.load(os.path.join(G, "losses_misc.npz"))
+    a, b, conf, disp = (torch.tensor(d[k]) for k in ("a", "b", "conf", "disp"))
+    assert abs(float(metrics.l1_loss_with_conf(a, b, conf)) - float(d["l1_conf"])) <= 1e-7
+    assert abs(float(metrics.l2_loss(a, b)) - float(d["l2"])) <= 1e-7
+    assert abs(float(metrics.smooth_loss(disp, a)) - float(d["smooth"])) <= 1e-6
+    np.testing.assert_allclose(metrics.mse(a, b).numpy(), d["mse"], rtol=1e-6)
