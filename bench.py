@@ -239,7 +239,8 @@ def main():
         achieved = B / (kernels_ms[dom] * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload, dom),
-                    "algorithmic_bytes_per_launch": int(B), "avg_launch_ms": round(kernels_ms[dom], 4)}
+                    "algorithmic_bytes_per_launch": int(B), "avg_launch_ms": round(kernels_ms[dom], 4),
+                    "valu": pmc_valu(args.workload, dom)}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
@@ -278,6 +279,19 @@ def pmc_traffic(workload, kernel):
     try:
         k = json.load(open(path))["kernels"][kernel]
         return int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
+
+
+def pmc_valu(workload, kernel):
+    """What actually bounds the blend kernels: VALU issue.  From the same committed PMC passes: wave-level VALU
+    instructions per launch and SIMD cycles per instruction (GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs;
+    a wave64 VALU instruction occupies its SIMD for 4 cycles, so ~4 means the SIMDs do nothing but issue)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel]
+        return {"wave_instructions_per_launch": int(k["SQ_INSTS_VALU"]),
+                "simd_cycles_per_wave_instruction": round(k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / k["SQ_INSTS_VALU"], 2)}
     except Exception:
         return None
 

@@ -42,6 +42,9 @@ if len(sys.argv) >= 4:
         if key and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
             kern[key] = {"FETCH_SIZE": round(agg[k]["FETCH_SIZE"] / max(cnt[k]["FETCH_SIZE"], 1), 1),
                          "WRITE_SIZE": round(agg[k]["WRITE_SIZE"] / max(cnt[k]["WRITE_SIZE"], 1), 1)}
+            for c in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):  # VALU issue rate (the blend kernels' real bound)
+                if c in agg[k]:
+                    kern[key][c] = round(agg[k][c] / max(cnt[k][c], 1), 1)
     json.dump({"workload": sys.argv[3],
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, mean per dispatch, KiB "
                          "(tools/profile_gpu.sh)",
