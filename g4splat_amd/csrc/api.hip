@@ -171,10 +171,12 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     return G4S_OK;
 }
 
-extern "C" int g4s_rasterizer_forward(
+// shs_rest == NULL: shs is the packed [P,M,3] tensor; otherwise shs = [P,1,3] and shs_rest = [P,M-1,3]
+static int rasterizer_forward_impl(
     g4s_resize_fn geometry_buffer, void* geometry_ctx, g4s_resize_fn binning_buffer, void* binning_ctx,
     g4s_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,
-    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+    const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
+    const float* scales,
     float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
     const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
     float* out_others, int* radii, int debug, void* stream_) {
@@ -238,7 +240,8 @@ extern "C" int g4s_rasterizer_forward(
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.cam_pos = cam_pos;
         pa.scale_modifier = scale_modifier;
-        pa.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16));
+        pa.shs_rest = shs_rest;
+        pa.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16));
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
         pa.depth_keys = keys_a;
         pa.ref_block_sums = (uint32_t*)(geom + GL.ref_block_sums);
@@ -336,20 +339,51 @@ extern "C" int g4s_rasterizer_forward(
     return R;
 }
 
+extern "C" int g4s_rasterizer_forward(
+    g4s_resize_fn geometry_buffer, void* geometry_ctx, g4s_resize_fn binning_buffer, void* binning_ctx,
+    g4s_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,
+    float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+    float* out_others, int* radii, int debug, void* stream) {
+    return rasterizer_forward_impl(geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D,
+                                   M, background, width, height, means3D, shs, nullptr, colors_precomp, opacities, scales,
+                                   scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
+                                   tan_fovy, prefiltered, out_color, out_others, radii, debug, stream);
+}
+
+extern "C" int g4s_rasterizer_forward_split_sh(
+    g4s_resize_fn geometry_buffer, void* geometry_ctx, g4s_resize_fn binning_buffer, void* binning_ctx,
+    g4s_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* sh_dc, const float* sh_rest, const float* opacities, const float* scales,
+    float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
+    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+    float* out_others, int* radii, int debug, void* stream) {
+    t_err[0] = 0;
+    if (P > 0 && (!sh_dc || M < 1 || (M > 1 && !sh_rest)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "split SH needs sh_dc [P,1,3] and, for M > 1, sh_rest [P,M-1,3]");
+    // M == 1: there is no rest tensor; the packed layout [P,1,3] is the same memory
+    return rasterizer_forward_impl(geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D,
+                                   M, background, width, height, means3D, sh_dc, M > 1 ? sh_rest : nullptr, nullptr, opacities,
+                                   scales, scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, cam_pos,
+                                   tan_fovx, tan_fovy, prefiltered, out_color, out_others, radii, debug, stream);
+}
+
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
     // gradient records | folded per-Gaussian sums | one validity byte per record
     return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + align_up((size_t)(P > 0 ? P : 1) * GRAD_FLOATS * 4) +
            align_up((size_t)(R > 0 ? R : 1)) + 256;
 }
 
-extern "C" int g4s_rasterizer_backward(
+static int rasterizer_backward_impl(
     int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-    const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* shs, const float* shs_rest, const float* colors_precomp, const float* scales, float scale_modifier,
+    const float* rotations,
     const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
     float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
-    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
-    char* workspace, size_t workspace_bytes, int debug, void* stream_) {
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
+    float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream_) {
     (void)scale_modifier;
     hipStream_t stream = (hipStream_t)stream_;
     t_err[0] = 0;
@@ -358,7 +392,7 @@ extern "C" int g4s_rasterizer_backward(
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
         return fail(G4S_ERR_INVALID_ARGUMENT, "state buffers must not be NULL");
     if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
-        !dL_dtransMat || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
+        !dL_dtransMat || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh) || (shs_rest && M > 1 && !dL_dsh_rest))
         return fail(G4S_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
     if (workspace_bytes < g4s_rasterizer_backward_workspace(P, R) || !workspace)
         return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
@@ -378,7 +412,11 @@ extern "C" int g4s_rasterizer_backward(
 
     // dL_dsh is mostly zero rows (invisible Gaussians): fill it once at memset speed, K8 only writes
     // the visible rows.  Issued ahead of the (VALU-bound) blend backward.
-    if (M > 0) HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * M * 3 * sizeof(float), stream));
+    if (M > 0 && shs_rest == nullptr) HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * M * 3 * sizeof(float), stream));
+    if (M > 0 && shs_rest != nullptr) {
+        HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * 3 * sizeof(float), stream));
+        if (M > 1) HIP_TRY(hipMemsetAsync(dL_dsh_rest, 0, (size_t)P * (M - 1) * 3 * sizeof(float), stream));
+    }
     // gradient records: only instances that receive a contribution are written by the blend backward; instead of
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
     float* gsum = (float*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));
@@ -415,13 +453,48 @@ extern "C" int g4s_rasterizer_backward(
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
     pb.gsum = gsum; pb.rec_flag = rec_flag;
-    pb.sh_vec16 = (shs != nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
+    pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest;
+    pb.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dtransMat = dL_dtransMat; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
     pb.dL_drot = dL_drot;
     { ProfScope ps(PF_PREPROCESS_BWD, stream); launch_preprocess_bwd(pb, stream); }
     CHECK_LAUNCH("preprocess_bwd");
     return G4S_OK;
+}
+
+extern "C" int g4s_rasterizer_backward(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+    const float* shs, const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    char* workspace, size_t workspace_bytes, int debug, void* stream) {
+    return rasterizer_backward_impl(P, D, M, R, background, width, height, means3D, shs, nullptr, colors_precomp, scales,
+                                    scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos, tan_fovx,
+                                    tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths,
+                                    dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh, nullptr,
+                                    dL_dscale, dL_drot, workspace, workspace_bytes, debug, stream);
+}
+
+extern "C" int g4s_rasterizer_backward_split_sh(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+    const float* sh_dc, const float* sh_rest, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale,
+    float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream) {
+    t_err[0] = 0;
+    if (P > 0 && (!sh_dc || M < 1 || (M > 1 && (!sh_rest || !dL_dsh_rest))))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "split SH needs sh_dc / dL_dsh_dc and, for M > 1, sh_rest / dL_dsh_rest");
+    return rasterizer_backward_impl(P, D, M, R, background, width, height, means3D, sh_dc, M > 1 ? sh_rest : nullptr, nullptr,
+                                    scales, scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos,
+                                    tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths,
+                                    dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh_dc,
+                                    M > 1 ? dL_dsh_rest : nullptr, dL_dscale, dL_drot, workspace, workspace_bytes, debug,
+                                    stream);
 }
 
 extern "C" int g4s_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix,

@@ -127,6 +127,7 @@ struct PreprocessArgs {
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;
     bool sh_vec16;  // shs is [P,16,3] on a 16-byte aligned base
+    const float* shs_rest;  // split layout (g4s_rasterizer_forward_split_sh): shs = [P,1,3], shs_rest = [P,M-1,3]; NULL = packed
     float* rec;
     uint8_t* clamped;
     uint32_t* tiles_touched;
@@ -215,6 +216,8 @@ struct PreprocessBwdArgs {
     const uint8_t* rec_flag;
     float* gsum;  // P x 18 folded gradient terms (workspace)
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
+    const float* shs_rest;  // split layout: shs / dL_dsh are the [P,1,3] parts, shs_rest / dL_dsh_rest the [P,M-1,3] ones
+    float* dL_dsh_rest;
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
         *dL_drot;
 };

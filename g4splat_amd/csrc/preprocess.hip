@@ -198,11 +198,20 @@ __device__ __forceinline__ bool lowpass_never_matters(const float* T, float cx, 
 }
 
 // Loads the 3*(deg+1)^2 active SH floats of Gaussian idx into registers.  vec16: the records are
-// 192 B ([16][3] floats) on a 16-byte aligned base, so they are fetched as 16-byte quads.
-__device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int deg, bool vec16,
-                                        float* sh /*48*/) {
+// 192 B ([16][3] floats) on a 16-byte aligned base, so they are fetched as 16-byte quads.  rest != NULL: split
+// layout, coefficient 0 lives in shs[P][3] and coefficients 1..M-1 in rest[P][M-1][3] (the two parameter tensors
+// of the reference's GaussianModel, 2dgs/scene/gaussian_model.py:  get_features = cat(_features_dc, _features_rest)).
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, const float* __restrict__ rest, size_t idx, int M,
+                                        int deg, bool vec16, float* sh /*48*/) {
     const int n = 3 * (deg + 1) * (deg + 1);
-    if (vec16) {
+    if (rest != nullptr) {
+        const float* p0 = shs + idx * 3;
+        const float* p1 = rest + idx * (size_t)(M - 1) * 3;
+        sh[0] = p0[0]; sh[1] = p0[1]; sh[2] = p0[2];
+#pragma unroll
+        for (int i = 3; i < 48; i++)
+            if (i < n) sh[i] = p1[i - 3];
+    } else if (vec16) {
         const float4* p = reinterpret_cast<const float4*>(shs + idx * 48);
 #pragma unroll
         for (int q = 0; q < 12; q++) {
@@ -308,7 +317,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         float rgb[3];
                         if (a.colors_precomp == nullptr) {
                             float sh[48];
-                            load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+                            load_sh(a.shs, a.shs_rest, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
                             sh_to_rgb(a.D, sh, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), rgb, clamp_bits);
                         } else {
                             rgb[0] = a.colors_precomp[3 * (size_t)idx];
@@ -425,7 +434,8 @@ __device__ __forceinline__ F3 dnormvdv(F3 v, F3 dv) {
 // backward.cu:20-139.  Writes all M coefficients of dL_dsh (zeros above the active degree)
 // and returns the view-direction term to add to dL_dmean.
 __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 pos, F3 campos, uint32_t clamp_bits,
-                                          const float* dL_dcolor, float* __restrict__ dsh, bool vec16) {
+                                          const float* dL_dcolor, float* __restrict__ dsh, float* __restrict__ dsh_rest,
+                                          bool vec16) {
     const F3 dir_orig = mk3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
     const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
     const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
@@ -488,7 +498,18 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
         }
     }
     const int nact = (deg + 1) * (deg + 1);
-    if (vec16) {  // M == 16, 16-byte aligned 192-byte record: twelve 16-byte stores
+    if (dsh_rest != nullptr) {  // split layout: dsh = this Gaussian's [3], dsh_rest = its [M-1][3]
+        dsh[0] = coef[0] * dRGB[0]; dsh[1] = coef[0] * dRGB[1]; dsh[2] = coef[0] * dRGB[2];
+#pragma unroll
+        for (int i = 1; i < 16; i++) {
+            if (i < M) {
+                const float cf = (i < nact) ? coef[i] : 0.0f;
+                dsh_rest[3 * (i - 1) + 0] = cf * dRGB[0]; dsh_rest[3 * (i - 1) + 1] = cf * dRGB[1];
+                dsh_rest[3 * (i - 1) + 2] = cf * dRGB[2];
+            }
+        }
+        for (int i = 45; i < (M - 1) * 3; i++) dsh_rest[i] = 0.0f;
+    } else if (vec16) {  // M == 16, 16-byte aligned 192-byte record: twelve 16-byte stores
         float o[48];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -694,7 +715,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     float dT_out[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) dT_out[i] = g[6 + i];
-    float* dsh = a.M > 0 ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr;
+    const bool split_sh = a.shs_rest != nullptr;
+    float* dsh = a.M > 0 ? a.dL_dsh + (size_t)idx * (split_sh ? 1 : a.M) * 3 : nullptr;
+    float* dsh_rest = split_sh ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 : nullptr;
 
     if (visible) {
         const bool precomp = (a.scales == nullptr);
@@ -792,9 +815,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         }
         if (a.shs != nullptr) {
             float sh[48];
-            load_sh(a.shs, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+            load_sh(a.shs, a.shs_rest, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
             const F3 dm = sh_backward(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
-                                      mk3(a.campos[0], a.campos[1], a.campos[2]), a.clamped[idx], g, dsh, a.sh_vec16);
+                                      mk3(a.campos[0], a.campos[1], a.campos[2]), a.clamped[idx], g, dsh, dsh_rest, a.sh_vec16);
             dmean3[0] += dm.x;
             dmean3[1] += dm.y;
             dmean3[2] += dm.z;

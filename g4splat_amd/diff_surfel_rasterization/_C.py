@@ -8,6 +8,8 @@ Same three entry points, same argument order, same tuple orders, same error beha
     rasterize_gaussians_backward(...)  -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat,
                                            dL_dsh, dL_dscales, dL_drotations)
                                           dsr/rasterize_points.h:40-63, rasterize_points.cu:136-233
+                                          (extension: `sh` may be the pair (features_dc, features_rest); dL_dsh is
+                                          then the pair of their gradients -- no concatenation on either side)
     mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]      rasterize_points.cu:235-254
 
 torch is plumbing here (device memory, current stream); all compute is in the HIP library.
@@ -61,6 +63,14 @@ class _Scratch:
         self.cb = _lib.RESIZE_FN(_resize)
 
 
+def _check_split_sh(sh_dc, sh_rest, means3D, colors):
+    P = int(means3D.size(0))
+    if sh_dc.ndim != 3 or tuple(sh_dc.shape) != (P, 1, 3) or sh_rest.ndim != 3 or sh_rest.size(0) != P or sh_rest.size(2) != 3:
+        raise RuntimeError("split SH must be (features_dc [P,1,3], features_rest [P,M-1,3])")
+    if colors is not None and colors.numel():
+        raise RuntimeError("provide split SHs or precomputed colours, not both")
+
+
 def _raise(code, what):
     raise RuntimeError(f"{what} failed ({code}): {_lib.last_error()}")
 
@@ -70,10 +80,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         prefiltered, debug):
     if means3D.ndim != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    split = isinstance(sh, (tuple, list))  # extension: (features_dc [P,1,3], features_rest [P,M-1,3]), never concatenated
+    sh_dc, sh_rest = sh if split else (sh, None)
     for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("opacity", opacity),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
-                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos)):
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh_dc), ("campos", campos)) + (
+                        (("sh_rest", sh_rest),) if split else ()):
         _check_cuda(t, name)
+    if split:
+        _check_split_sh(sh_dc, sh_rest, means3D, colors)
     lib = _lib.load()
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     dev = means3D.device
@@ -86,16 +101,26 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         out_color = torch.empty((NUM_CHANNELS, H, W), **fopt)
         out_others = torch.empty((7, H, W), **fopt)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        M = int(sh.size(1)) if sh.size(0) != 0 else 0
         bg, m3, col, opa = _f32c(background), _f32c(means3D), _f32c(colors), _f32c(opacity)
         sc, rot, tm = _f32c(scales, 8), _f32c(rotations, 16), _f32c(transMat_precomp)
-        vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh, 16), _f32c(campos)
+        vm, pm, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rendered = lib.g4s_rasterizer_forward(
-            geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(shc),
-            _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp),
-            float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(out_color), _ptr(out_others), _ptr(radii),
-            int(bool(debug)), stream)
+        if split:
+            M = 1 + int(sh_rest.size(1))
+            dc, rest = _f32c(sh_dc), _f32c(sh_rest)
+            rendered = lib.g4s_rasterizer_forward_split_sh(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(dc),
+                _ptr(rest), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm),
+                _ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(out_color), _ptr(out_others),
+                _ptr(radii), int(bool(debug)), stream)
+        else:
+            M = int(sh.size(1)) if sh.size(0) != 0 else 0
+            shc = _f32c(sh, 16)
+            rendered = lib.g4s_rasterizer_forward(
+                geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(shc),
+                _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm),
+                _ptr(cp), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), _ptr(out_color), _ptr(out_others),
+                _ptr(radii), int(bool(debug)), stream)
         for s in (geom, binning, img):
             if s.error is not None:
                 raise s.error
@@ -111,15 +136,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     """`out` (extension over the reference): optional dict name -> preallocated float32 tensor for any of the
     returned gradients, e.g. views of a persistent all-reduce bucket (parallel.py); the library writes every
     element of them, so no packing copy is needed before the collective."""
+    split = isinstance(sh, (tuple, list))
+    sh_dc, sh_rest = sh if split else (sh, None)
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
                     ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
-                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh), ("campos", campos),
-                    ("binningBuffer", binningBuffer), ("imageBuffer", imageBuffer), ("geomBuffer", geomBuffer)):
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh_dc), ("campos", campos),
+                    ("binningBuffer", binningBuffer), ("imageBuffer", imageBuffer), ("geomBuffer", geomBuffer)) + (
+                        (("sh_rest", sh_rest),) if split else ()):
         _check_cuda(t, name)
+    if split:
+        _check_split_sh(sh_dc, sh_rest, means3D, colors)
     lib = _lib.load()
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
-    M = int(sh.size(1)) if sh.size(0) != 0 else 0
+    M = (1 + int(sh_rest.size(1))) if split else (int(sh.size(1)) if sh.size(0) != 0 else 0)
     dev = means3D.device
     with torch.cuda.device(dev):
         fopt = dict(dtype=torch.float32, device=dev)
@@ -144,7 +174,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dnormal = make((P, 3), **fopt)
         dL_dopacity = make((P, 1), "dL_dopacity", **fopt)
         dL_dtransMat = make((P, 9), "dL_dtransMat", **fopt)
-        dL_dsh = make((P, M, 3), "dL_dsh", **fopt)
+        if split:
+            dL_dsh = (make((P, 1, 3), "dL_dsh_dc", **fopt), make((P, M - 1, 3), "dL_dsh_rest", **fopt))
+        else:
+            dL_dsh = make((P, M, 3), "dL_dsh", **fopt)
         dL_dscales = make((P, 2), "dL_dscales", 8, **fopt)
         dL_drotations = make((P, 4), "dL_drotations", 16, **fopt)
         if given:
@@ -154,17 +187,28 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
             sc, rot, tm = _f32c(scales, 8), _f32c(rotations, 16), _f32c(transMat_precomp)
-            vm, pm, shc, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(sh, 16), _f32c(campos)
+            vm, pm, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
             gc, go = _f32c(dL_dout_color), _f32c(dL_dout_others)
             rad = radii.contiguous()
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            rc = lib.g4s_rasterizer_backward(
-                P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc),
-                float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx),
-                float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
-                _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
-                _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
-                _ptr(workspace), ws_bytes, int(bool(debug)), stream)
+            if split:
+                dc, rest = _f32c(sh_dc), _f32c(sh_rest)
+                rc = lib.g4s_rasterizer_backward_split_sh(
+                    P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(dc), _ptr(rest), _ptr(sc),
+                    float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx),
+                    float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
+                    _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                    _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(dL_dsh[0]), _ptr(dL_dsh[1]), _ptr(dL_dscales),
+                    _ptr(dL_drotations), _ptr(workspace), ws_bytes, int(bool(debug)), stream)
+            else:
+                shc = _f32c(sh, 16)
+                rc = lib.g4s_rasterizer_backward(
+                    P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(shc), _ptr(col), _ptr(sc),
+                    float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx),
+                    float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
+                    _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                    _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                    _ptr(workspace), ws_bytes, int(bool(debug)), stream)
             if rc != 0:
                 _raise(rc, "rasterize_gaussians_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dtransMat, dL_dsh, dL_dscales, dL_drotations

@@ -89,8 +89,48 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_rotations, grad_cov3Ds_precomp, None)
 
 
+class _RasterizeGaussiansSplitSH(torch.autograd.Function):
+    """Same node with the SH coefficients given as the model's two parameter tensors (features_dc [P,1,3],
+    features_rest [P,M-1,3]) instead of their concatenation: the library reads them in place and writes the two
+    gradients separately (include/g4s_rasterizer.h, g4s_rasterizer_*_split_sh).  Extension over the reference."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh_dc, sh_rest, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        fwd_args = (rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
+                    (sh_dc, sh_rest), rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*fwd_args)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, radii, sh_dc, sh_rest, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        (means3D, scales, rotations, cov3Ds_precomp, radii, sh_dc, sh_rest, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        (grad_means2D, _grad_colors, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, empty, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, (sh_dc, sh_rest), rs.sh_degree,
+            rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
+        return (grad_means3D, grad_means2D, grad_sh[0], grad_sh[1], grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    if isinstance(sh, (tuple, list)):
+        if colors_precomp is not None and colors_precomp.numel():
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        return _RasterizeGaussiansSplitSH.apply(means3D, means2D, sh[0], sh[1], opacities, scales, rotations,
+                                                cov3Ds_precomp, raster_settings)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 
@@ -118,7 +158,7 @@ class GaussianRasterizer(nn.Module):
         def absent():  # empty tensor == "not given" for the native side
             return torch.empty(0, dtype=torch.float32, device=means3D.device)
 
-        shs = absent() if shs is None else shs
+        shs = absent() if shs is None else shs  # (features_dc, features_rest) is passed through: split-SH extension
         colors_precomp = absent() if colors_precomp is None else colors_precomp
         scales = absent() if scales is None else scales
         rotations = absent() if rotations is None else rotations

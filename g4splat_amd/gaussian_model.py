@@ -67,6 +67,12 @@ class GaussianModel(DensifyMixin):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
     @property
+    def get_features_split(self):
+        """(features_dc [P,1,3], features_rest [P,M-1,3]) for the rasterizer's split-SH entry points: what
+        `get_features` concatenates, handed over in place (extension over the reference)."""
+        return (self._features_dc, self._features_rest)
+
+    @property
     def get_opacity(self):
         o = torch.sigmoid(self._opacity)
         if self.use_mip_filter:

@@ -52,7 +52,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     shs = colors_precomp = None
     if override_color is None:
-        shs = pc.get_features  # convert_SHs_python is forced off in the reference (:82)
+        # convert_SHs_python is forced off in the reference (:82).  The reference concatenates the two SH parameter
+        # tensors here (pc.get_features); the HIP rasterizer reads them where they are (split-SH entry points), which
+        # saves the concatenation and the slicing of its gradient -- 4 x P x 192 B per iteration.
+        split = getattr(pc, "get_features_split", None) if rasterizer_cls is None else None
+        shs = split if split is not None else pc.get_features
     else:
         colors_precomp = override_color
 

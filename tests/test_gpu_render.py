@@ -169,3 +169,58 @@ def test_pack_rows_roundtrip(hip_lib):
     for s, b in zip(segs, before):
         assert torch.equal(s[idx], 2.0 * b[idx]) and torch.equal(s[keep], b[keep])
     assert hip_lib.g4s_pack_rows(9, ptrs, wid, None, 0, None, 0, stream) < 0
+
+
+@pytest.mark.parametrize("D,M", [(3, 16), (1, 16), (0, 16), (2, 9), (0, 1)])
+def test_split_sh_is_bitwise_the_packed_path(hip_lib, D, M):
+    """g4s_rasterizer_*_split_sh (features_dc / features_rest read in place, gradients written separately) against
+    the packed [P,M,3] entry points: identical images, radii and gradients, bit for bit."""
+    from common import scene_inputs
+    from g4splat_amd.diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    inp = scene_inputs(P=30000, W=320, H=208, seed=40 + D, D=3, bg=(0.2, 0.1, 0.3), scale_mul=0.8)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    sh_all = t(inp["sh"])[:, :M, :].contiguous()
+    rs = GaussianRasterizationSettings(
+        image_height=inp["H"], image_width=inp["W"], tanfovx=inp["tanfovx"], tanfovy=inp["tanfovy"], bg=t(inp["bg"]),
+        scale_modifier=1.0, viewmatrix=t(inp["view"]), projmatrix=t(inp["proj"]), sh_degree=D,
+        campos=t(inp["campos"]), prefiltered=False, debug=False)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    w_c = torch.randn((3, inp["H"], inp["W"]), generator=gen).to(dev)
+    w_o = torch.randn((7, inp["H"], inp["W"]), generator=gen).to(dev)
+
+    def run(split):
+        leaves = {k: t(inp[k]).requires_grad_(True) for k in ("means3D", "opacity", "scales", "rotations")}
+        m2 = torch.zeros_like(leaves["means3D"], requires_grad=True)
+        if split:
+            dc = sh_all[:, :1, :].clone().requires_grad_(True)
+            rest = sh_all[:, 1:, :].clone().requires_grad_(True)
+            shs = (dc, rest)
+        else:
+            packed = sh_all.clone().requires_grad_(True)
+            shs = packed
+        color, radii, others = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacity"],
+                                                      shs=shs, scales=leaves["scales"], rotations=leaves["rotations"])
+        ((color * w_c).sum() + (others * w_o).sum()).backward()
+        g_sh = torch.cat((dc.grad, rest.grad), dim=1) if split else packed.grad
+        return color.detach(), radii, others.detach(), g_sh, m2.grad, {k: v.grad for k, v in leaves.items()}
+
+    a, b = run(False), run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert a[3].abs().max() > 0
+    if (D + 1) ** 2 < M:
+        assert a[3][:, (D + 1) ** 2:, :].abs().max() == 0  # coefficients above the active degree get zero gradient
+    for k in a[5]:
+        assert torch.equal(a[5][k], b[5][k]), k
+
+
+def test_split_sh_argument_errors(hip_lib):
+    from g4splat_amd.diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    z = lambda *s: torch.zeros(s, device=dev)
+    bad = (z(10, 3), z(10, 15, 3))  # features_dc must be [P,1,3]
+    with pytest.raises(RuntimeError, match="split SH"):
+        _C.rasterize_gaussians(z(3), z(10, 3), z(0), z(10, 1), z(10, 2), z(10, 4), 1.0, z(0), z(4, 4), z(4, 4), 1.0, 1.0,
+                               32, 32, bad, 3, z(3), False, False)
