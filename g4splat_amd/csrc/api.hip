@@ -571,6 +571,23 @@ extern "C" int g4s_adam_step(int nseg, float* const* params, const float* const*
 }
 
 // ---- packed rows for the visible-rows gradient exchange ------------------------------------------
+extern "C" void g4s_densify_stats_launch_internal(int P, const float* grad, const unsigned char* filter, const int* radii,
+                                                  float* accum, float* denom, float* max_radii, hipStream_t s);
+
+extern "C" int g4s_densify_stats(int P, const float* grad_mean2D, const unsigned char* update_filter, const int* radii,
+                                 float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P must not be negative");
+    if (P == 0) return G4S_OK;
+    if (!grad_mean2D || !update_filter || !xyz_gradient_accum || !denom || (max_radii2D && !radii))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    g4s_densify_stats_launch_internal(P, grad_mean2D, update_filter, radii, xyz_gradient_accum, denom, max_radii2D, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(G4S_ERR_HIP, "densify_stats launch: %s", hipGetErrorString(e));
+    return G4S_OK;
+}
+
 extern "C" void g4s_pack_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, const long long* idx, int n,
                                               float* packed, int unpack, hipStream_t s);
 

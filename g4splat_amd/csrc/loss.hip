@@ -248,7 +248,29 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs a) {
         for (int i = 0; i < cnt; i++) { p[i] = pv[i]; m[i] = mv[i]; v[i] = vv[i]; }
     }
 }
+
+// Densification statistics of one view (2dgs/scene/gaussian_model.py:649-651 and the max_radii2D update of the
+// training loop, train_with_refine_depth.py): for the Gaussians selected by `filter`
+//   xyz_gradient_accum += |dL/dmean2D|_2,  denom += 1,  max_radii2D = max(max_radii2D, radii)
+// in one pass (28 B per Gaussian) instead of boolean-mask gathers, a norm and scatters (about twenty launches).
+__global__ void __launch_bounds__(256) densify_stats_kernel(int P, const float* __restrict__ grad, const uint8_t* __restrict__ filter,
+                                                            const int* __restrict__ radii, float* __restrict__ accum,
+                                                            float* __restrict__ denom, float* __restrict__ max_radii) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= P || !filter[i]) return;
+    const float gx = grad[3 * i], gy = grad[3 * i + 1], gz = grad[3 * i + 2];
+    accum[i] += sqrtf((gx * gx + gy * gy) + gz * gz);
+    denom[i] += 1.0f;
+    if (max_radii != nullptr) max_radii[i] = fmaxf(max_radii[i], (float)radii[i]);
+}
 }  // namespace g4s
+
+extern "C" void g4s_densify_stats_launch_internal(int P, const float* grad, const unsigned char* filter, const int* radii,
+                                                  float* accum, float* denom, float* max_radii, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(g4s::densify_stats_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, grad, filter, radii,
+                       accum, denom, max_radii);
+}
 
 extern "C" void g4s_adam_launch_internal(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
                                          float* const* exp_avg_sq, const long long* numel, const double* lr, const int* step,

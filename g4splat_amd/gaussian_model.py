@@ -204,11 +204,20 @@ class GaussianModel(DensifyMixin):
         return attribute_names(self._features_rest.shape[1], self._scaling.shape[1], self._rotation.shape[1],
                                self.use_mip_filter)
 
-    def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        """gaussian_model.py:649-651: accumulate the per-view norm of the screen-space gradient."""
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1,
-                                                             keepdim=True)
+    def add_densification_stats(self, viewspace_point_tensor, update_filter, radii=None):
+        """gaussian_model.py:649-651: accumulate the per-view norm of the screen-space gradient.  `radii` (extension):
+        also fold the training loop's `max_radii2D[filter] = max(max_radii2D[filter], radii[filter])` in.  On a HIP
+        device this is one fused kernel (optim.densify_stats); host tensors take the reference's torch formulation."""
+        grad = viewspace_point_tensor.grad
+        if grad.is_cuda:
+            from .optim import densify_stats
+            densify_stats(grad, update_filter, self.xyz_gradient_accum, self.denom, radii,
+                          self.max_radii2D if radii is not None else None)
+            return
+        self.xyz_gradient_accum[update_filter] += torch.norm(grad[update_filter], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
+        if radii is not None:
+            self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter], radii[update_filter].float())
 
     # ---- on-disk format (gaussian_model.py:293-315, 441-493) ----------------------------------
     def save_ply(self, path):

@@ -64,3 +64,35 @@ class FusedAdam(torch.optim.Optimizer):
                     if rc != 0:
                         raise RuntimeError(f"g4s_adam_step failed ({rc}): {_lib.last_error()}")
         return loss
+
+
+@torch.no_grad()
+def densify_stats(grad_mean2D, update_filter, xyz_gradient_accum, denom, radii=None, max_radii2D=None):
+    """One-kernel form of GaussianModel.add_densification_stats (gaussian_model.py:649-651) plus, when `radii` and
+    `max_radii2D` are given, the training loop's max_radii2D update (include/g4s_optim.h, g4s_densify_stats).
+    All tensors on one HIP device; statistics are updated in place."""
+    P = int(grad_mean2D.shape[0])
+    dev = grad_mean2D.device
+    if not grad_mean2D.is_cuda:
+        raise RuntimeError("densify_stats: HIP tensors only")
+    if (tuple(grad_mean2D.shape) != (P, 3) or grad_mean2D.dtype != torch.float32 or update_filter.dtype != torch.bool
+            or update_filter.numel() != P or xyz_gradient_accum.numel() != P or denom.numel() != P):
+        raise RuntimeError("densify_stats: expected grad [P,3] float32, filter bool [P], statistics float32 [P(,1)]")
+    for t in (xyz_gradient_accum, denom) + ((max_radii2D,) if max_radii2D is not None else ()):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise RuntimeError("densify_stats: statistics must be contiguous float32 tensors on the gradient's device")
+    if (radii is None) != (max_radii2D is None):
+        raise RuntimeError("densify_stats: give radii and max_radii2D together")
+    g, f = grad_mean2D.contiguous(), update_filter.contiguous()
+    r = radii.contiguous() if radii is not None else None
+    if r is not None and (r.dtype != torch.int32 or r.numel() != P or max_radii2D.numel() != P):
+        raise RuntimeError("densify_stats: radii must be int32 [P]")
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.g4s_densify_stats(P, ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(f.data_ptr()),
+                                   ctypes.c_void_p(r.data_ptr() if r is not None else 0),
+                                   ctypes.c_void_p(xyz_gradient_accum.data_ptr()), ctypes.c_void_p(denom.data_ptr()),
+                                   ctypes.c_void_p(max_radii2D.data_ptr() if max_radii2D is not None else 0),
+                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"g4s_densify_stats failed ({rc}): {_lib.last_error()}")

@@ -30,6 +30,19 @@ int g4s_adam_step(int nseg, float* const* params, const float* const* grads, flo
                   float* const* exp_avg_sq, const long long* numel, const double* lr, const int* step, double beta1,
                   double beta2, double eps, void* stream);
 
+/*
+ * Densification statistics of one rendered view, fused.  Replaces GaussianModel.add_densification_stats
+ * (2d-gaussian-splatting/scene/gaussian_model.py:649-651) and the max_radii2D update of the training loop
+ * (train_with_refine_depth.py, "max_radii2D[visibility_filter] = max(max_radii2D[visibility_filter], radii[...])"):
+ * for every i with update_filter[i] != 0
+ *     xyz_gradient_accum[i] += || grad_mean2D[i, 0:3] ||_2      denom[i] += 1
+ *     max_radii2D[i] = max(max_radii2D[i], radii[i])            (skipped when max_radii2D is NULL)
+ * grad_mean2D [P,3] is the rasterizer's dL_dmean2D (the gradient of `viewspace_points`), update_filter one byte
+ * per Gaussian (a torch bool tensor), radii int32 [P]; the three statistics are float32 [P], updated in place.
+ */
+int g4s_densify_stats(int P, const float* grad_mean2D, const unsigned char* update_filter, const int* radii,
+                      float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,3 +115,34 @@ def test_speed_vs_torch_adam(hip_lib, capsys):
         print("\nadam timing:", json.dumps({"P": P, "torch_foreach_ms": round(t_ref, 3), "fused_ms": round(t_hip, 3),
                                             "fused_GBps": round(traffic / t_hip / 1e6, 1)}))
     assert t_hip < t_ref
+
+
+def test_fused_densification_stats_match_the_torch_formulation(hip_lib):
+    """g4s_densify_stats against GaussianModel.add_densification_stats' host formulation
+    (2dgs/scene/gaussian_model.py:649-651) + the training loop's max_radii2D update, over several views."""
+    from g4splat_amd.optim import densify_stats
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    P = 100_003
+    acc_h, den_h, mr_h = torch.zeros((P, 1)), torch.zeros((P, 1)), torch.zeros(P)
+    acc_d, den_d, mr_d = acc_h.to(dev), den_h.to(dev), mr_h.to(dev)
+    for view in range(4):
+        grad = torch.randn((P, 3), generator=g) * 1e-3
+        grad[:, 2] = 0
+        radii = torch.randint(0, 40, (P,), generator=g, dtype=torch.int32)
+        radii[torch.rand(P, generator=g) < 0.6] = 0
+        filt = radii > 0
+        acc_h[filt] += torch.norm(grad[filt], dim=-1, keepdim=True)
+        den_h[filt] += 1
+        mr_h[filt] = torch.max(mr_h[filt], radii[filt].float())
+        densify_stats(grad.to(dev), filt.to(dev), acc_d, den_d, radii.to(dev), mr_d)
+    torch.cuda.synchronize()
+    assert torch.equal(den_d.cpu(), den_h) and torch.equal(mr_d.cpu(), mr_h)
+    assert (acc_d.cpu() - acc_h).abs().max() <= 4e-7 * acc_h.abs().max()
+    # without radii: max_radii2D untouched
+    before = mr_d.clone()
+    densify_stats(torch.ones((P, 3), device=dev), torch.ones(P, dtype=torch.bool, device=dev), acc_d, den_d)
+    assert torch.equal(mr_d, before) and torch.equal(den_d.cpu(), den_h + 1)
+    with pytest.raises(RuntimeError):
+        densify_stats(torch.ones((P, 3), device=dev), torch.ones(P, dtype=torch.bool, device=dev), acc_d, den_d,
+                      radii=torch.zeros(P, dtype=torch.int32, device=dev))

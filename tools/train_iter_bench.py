@@ -60,8 +60,7 @@ def main():
         total = loss + 0.05 * normal_error.mean() + 100.0 * out["rend_dist"].mean()
         total.backward()
         with torch.no_grad():
-            model.max_radii2D = torch.maximum(model.max_radii2D, out["radii"].float())
-            model.add_densification_stats(out["viewspace_points"], out["visibility_filter"])
+            model.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
             model.optimizer.step()
             model.optimizer.zero_grad(set_to_none=True)
 
