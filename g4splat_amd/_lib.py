@@ -55,6 +55,9 @@ SIGNATURES = {
     # include/g4s_losses.h
     "g4s_photometric_workspace": (c_sz, [c_i, c_i]),
     "g4s_photometric_loss": (c_i, [c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_sz, c_p]),
+    "g4s_geometry_regularizers_workspace": (c_sz, [c_i, c_i]),
+    "g4s_geometry_regularizers_forward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "g4s_geometry_regularizers_backward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     # include/g4s_render_maps.h
     "g4s_render_maps_workspace": (c_sz, []),
     "g4s_render_maps_forward": (c_i, [c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz,

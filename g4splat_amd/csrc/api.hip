@@ -64,11 +64,11 @@ inline bool misaligned(const void* p, size_t a) { return p != nullptr && ((size_
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----
 enum ProfId { PF_PREPROCESS_FWD, PF_DEPTH_SORT, PF_COUNT_SCAN, PF_EMIT, PF_TILE_SORT, PF_TILE_RANGES, PF_BLEND_FWD,
-              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_PHOTO_LOSS, PF_ADAM, PF_COUNT };
+              PF_BLEND_BWD, PF_PREPROCESS_BWD, PF_MAPS_FWD, PF_MAPS_BWD, PF_PHOTO_LOSS, PF_ADAM, PF_GEO_REG, PF_COUNT };
 const char* const kProfNames[PF_COUNT] = {"preprocess_fwd", "depth_sort", "count_scan", "emit", "tile_sort",
                                           "tile_ranges",    "blend_fwd",  "blend_bwd",  "preprocess_bwd",
                                           "maps_fwd",       "maps_bwd",   "photometric_loss",
-                                          "adam"};
+                                          "adam", "geometry_regularizers"};
 struct ProfRec { int id; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
@@ -542,6 +542,43 @@ extern "C" int g4s_photometric_loss(int width, int height, const float* image, c
     { ProfScope ps(PF_PHOTO_LOSS, stream);
       g4s_photometric_launch_internal(width, height, image, gt, lambda_dssim, out3, dL_dimage, workspace, stream); }
     CHECK_LAUNCH("photometric_loss");
+    return G4S_OK;
+}
+
+extern "C" void g4s_georeg_launch_internal(int fwd, int W, int H, const float* rn, const float* sn, const float* dist, float* out2,
+                                           const float* g2, float* d_rn, float* d_sn, float* d_dist, char* workspace,
+                                           hipStream_t s);
+
+extern "C" int g4s_geometry_regularizers_forward(int width, int height, const float* rend_normal, const float* surf_normal,
+                                                 const float* rend_dist, float* out2, char* workspace, size_t workspace_bytes,
+                                                 void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "width, height must be positive");
+    if (!rend_normal || !surf_normal || !rend_dist || !out2) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (!workspace || workspace_bytes < g4s_geometry_regularizers_workspace(width, height))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    { ProfScope ps(PF_GEO_REG, stream);
+      g4s_georeg_launch_internal(1, width, height, rend_normal, surf_normal, rend_dist, out2, nullptr, nullptr, nullptr, nullptr,
+                                 workspace, stream); }
+    CHECK_LAUNCH("geometry_regularizers_forward");
+    return G4S_OK;
+}
+
+extern "C" int g4s_geometry_regularizers_backward(int width, int height, const float* rend_normal, const float* surf_normal,
+                                                  const float* grad_out2, float* dL_drend_normal, float* dL_dsurf_normal,
+                                                  float* dL_drend_dist, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "width, height must be positive");
+    if (!rend_normal || !surf_normal || !grad_out2 || !dL_drend_normal || !dL_dsurf_normal || !dL_drend_dist)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    { ProfScope ps(PF_GEO_REG, stream);
+      g4s_georeg_launch_internal(0, width, height, rend_normal, surf_normal, nullptr, nullptr, grad_out2, dL_drend_normal,
+                                 dL_dsurf_normal, dL_drend_dist, nullptr, stream); }
+    CHECK_LAUNCH("geometry_regularizers_backward");
     return G4S_OK;
 }
 

@@ -192,6 +192,124 @@ extern "C" void g4s_photometric_launch_internal(int W, int H, const float* image
     if (dL_dimage) hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, s, a);
 }
 
+// ---- geometry regularisers of the training step (include/g4s_losses.h) ------------------------------
+// normal_error.mean() = mean(1 - sum_c rend_normal_c surf_normal_c) and rend_dist.mean()
+// (train_with_refine_depth.py:391-396): one pass over the seven planes + a fixed-order reduction forward, one pass
+// backward, instead of ~8 element-wise / reduction launches each way.
+namespace g4s {
+struct GeoRegArgs {
+    long long N;  // pixels
+    int vec;      // N % 4 == 0 and every base 16-byte aligned
+    const float *rn, *sn, *dist;
+    float* partials;  // [blocks][2]
+    int nblocks;
+    float* out2;
+    const float* g2;
+    float *d_rn, *d_sn, *d_dist;
+};
+
+__global__ void __launch_bounds__(256) georeg_fwd_kernel(GeoRegArgs a) {
+    __shared__ float s_red[2][4];
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float e = 0.0f, d = 0.0f;
+    if (p0 < a.N) {
+        float r[3][4], n[3][4], t[4];
+        const int cnt = (int)((a.N - p0) < 4 ? (a.N - p0) : 4);
+        if (a.vec) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                *reinterpret_cast<float4*>(r[c]) = *reinterpret_cast<const float4*>(a.rn + c * a.N + p0);
+                *reinterpret_cast<float4*>(n[c]) = *reinterpret_cast<const float4*>(a.sn + c * a.N + p0);
+            }
+            *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(a.dist + p0);
+        } else {
+            for (int i = 0; i < 4; i++) {
+                const long long p = p0 + (i < cnt ? i : 0);
+                for (int c = 0; c < 3; c++) { r[c][i] = a.rn[c * a.N + p]; n[c][i] = a.sn[c * a.N + p]; }
+                t[i] = a.dist[p];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < cnt) {
+                e += 1.0f - ((r[0][i] * n[0][i] + r[1][i] * n[1][i]) + r[2][i] * n[2][i]);
+                d += t[i];
+            }
+        }
+    }
+    const float be = block_sum256(e, s_red[0]);
+    const float bd = block_sum256(d, s_red[1]);
+    if (threadIdx.x == 0) { a.partials[2 * blockIdx.x] = be; a.partials[2 * blockIdx.x + 1] = bd; }
+}
+
+__global__ void __launch_bounds__(256) georeg_reduce_kernel(GeoRegArgs a) {
+    __shared__ double s_e[256], s_d[256];
+    double e = 0, d = 0;
+    for (int i = (int)threadIdx.x; i < a.nblocks; i += 256) { e += a.partials[2 * i]; d += a.partials[2 * i + 1]; }
+    s_e[threadIdx.x] = e; s_d[threadIdx.x] = d;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s_e[threadIdx.x] += s_e[threadIdx.x + o]; s_d[threadIdx.x] += s_d[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.out2[0] = (float)(s_e[0] / (double)a.N);
+        a.out2[1] = (float)(s_d[0] / (double)a.N);
+    }
+}
+
+__global__ void __launch_bounds__(256) georeg_bwd_kernel(GeoRegArgs a) {
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= a.N) return;
+    const float inv = 1.0f / (float)a.N;
+    const float gn = -(a.g2[0] * inv), gd = a.g2[1] * inv;  // d mean / d element = 1/N, as autograd's mean backward
+    const int cnt = (int)((a.N - p0) < 4 ? (a.N - p0) : 4);
+    if (a.vec) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float4 r = *reinterpret_cast<const float4*>(a.rn + c * a.N + p0);
+            const float4 n = *reinterpret_cast<const float4*>(a.sn + c * a.N + p0);
+            *reinterpret_cast<float4*>(a.d_rn + c * a.N + p0) = make_float4(gn * n.x, gn * n.y, gn * n.z, gn * n.w);
+            *reinterpret_cast<float4*>(a.d_sn + c * a.N + p0) = make_float4(gn * r.x, gn * r.y, gn * r.z, gn * r.w);
+        }
+        *reinterpret_cast<float4*>(a.d_dist + p0) = make_float4(gd, gd, gd, gd);
+    } else {
+        for (int i = 0; i < cnt; i++) {
+            for (int c = 0; c < 3; c++) {
+                a.d_rn[c * a.N + p0 + i] = gn * a.sn[c * a.N + p0 + i];
+                a.d_sn[c * a.N + p0 + i] = gn * a.rn[c * a.N + p0 + i];
+            }
+            a.d_dist[p0 + i] = gd;
+        }
+    }
+}
+}  // namespace g4s
+
+extern "C" size_t g4s_geometry_regularizers_workspace(int width, int height) {
+    const size_t blocks = ((size_t)width * height + 1023) / 1024;
+    return g4s::align_up(blocks * 8) + 256;
+}
+
+static inline bool georeg_al16(const void* p) { return ((size_t)p & 15) == 0; }
+
+extern "C" void g4s_georeg_launch_internal(int fwd, int W, int H, const float* rn, const float* sn, const float* dist, float* out2,
+                                           const float* g2, float* d_rn, float* d_sn, float* d_dist, char* workspace,
+                                           hipStream_t s) {
+    using namespace g4s;
+    GeoRegArgs a{};
+    a.N = (long long)W * H;
+    a.rn = rn; a.sn = sn; a.dist = dist; a.out2 = out2; a.g2 = g2; a.d_rn = d_rn; a.d_sn = d_sn; a.d_dist = d_dist;
+    a.nblocks = (int)((a.N + 1023) / 1024);
+    a.vec = (a.N % 4 == 0) && georeg_al16(rn) && georeg_al16(sn) && (fwd ? georeg_al16(dist) : (georeg_al16(d_rn) && georeg_al16(d_sn) && georeg_al16(d_dist)));
+    if (fwd) {
+        a.partials = (float*)align_ptr(workspace);
+        hipLaunchKernelGGL(georeg_fwd_kernel, dim3(a.nblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(georeg_reduce_kernel, dim3(1), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(georeg_bwd_kernel, dim3(a.nblocks), dim3(256), 0, s, a);
+    }
+}
+
 // ---- fused Adam over up to eight parameter segments (include/g4s_optim.h) ------------------------------
 namespace g4s {
 struct AdamSegs {

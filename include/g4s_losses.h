@@ -33,6 +33,23 @@ size_t g4s_photometric_workspace(int width, int height);
 int g4s_photometric_loss(int width, int height, const float* image, const float* gt, float lambda_dssim, float* out3,
                          float* dL_dimage, char* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Geometry regularisers of the training step, fused (train_with_refine_depth.py:391-396):
+ *   out2[0] = mean over pixels of  1 - sum_c rend_normal[c] * surf_normal[c]     ("normal_error.mean()")
+ *   out2[1] = mean over pixels of  rend_dist                                      ("rend_dist.mean()")
+ * rend_normal, surf_normal [3,H,W], rend_dist [1,H,W] float32 (device), out2 device float[2]; the caller applies
+ * lambda_normal / lambda_dist.  Fixed-order reduction (bit-reproducible).  The backward takes the cotangents of the
+ * two means (device float[2]) and writes every element of the three gradients:
+ *   dL_drend_normal = -(g0/N) surf_normal,  dL_dsurf_normal = -(g0/N) rend_normal,  dL_drend_dist = g1/N.
+ */
+size_t g4s_geometry_regularizers_workspace(int width, int height);
+int g4s_geometry_regularizers_forward(int width, int height, const float* rend_normal, const float* surf_normal,
+                                      const float* rend_dist, float* out2, char* workspace, size_t workspace_bytes,
+                                      void* stream);
+int g4s_geometry_regularizers_backward(int width, int height, const float* rend_normal, const float* surf_normal,
+                                       const float* grad_out2, float* dL_drend_normal, float* dL_dsurf_normal,
+                                       float* dL_drend_dist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

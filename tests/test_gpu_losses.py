@@ -98,3 +98,32 @@ def test_errors(hip_lib):
         photometric_loss(a, torch.zeros((3, 8, 9), device="cuda:0"), 0.2)
     loss, l1, ss = photometric_loss(a, a, 0.2)  # identical images, no gradient requested
     assert float(l1) == 0.0 and abs(float(ss) - 1.0) <= 1e-6 and abs(float(loss)) <= 1e-6
+
+
+@pytest.mark.parametrize("H,W", [(1200, 1600), (37, 53)])
+def test_geometry_regularizers_match_torch(hip_lib, H, W):
+    """g4s_geometry_regularizers_* against the reference's formulation (train_with_refine_depth.py:391-396)."""
+    from g4splat_amd.losses import geometry_regularizers
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(s, generator=g).to(dev)
+    rn, sn, rd = mk(3, H, W), mk(3, H, W), mk(1, H, W).abs()
+    leaves_a = [t.clone().requires_grad_(True) for t in (rn, sn, rd)]
+    leaves_b = [t.clone().requires_grad_(True) for t in (rn, sn, rd)]
+    ne, dm = geometry_regularizers(*leaves_a)
+    (0.05 * ne + 100.0 * dm).backward()
+    normal_error = (1 - (leaves_b[0] * leaves_b[1]).sum(dim=0))[None]
+    ne_t, dm_t = normal_error.mean(), leaves_b[2].mean()
+    (0.05 * ne_t + 100.0 * dm_t).backward()
+    torch.cuda.synchronize()
+    # the fused means are accumulated in double; torch's float32 tree sum is the looser of the two
+    ref_ne = normal_error.double().mean().item()
+    ref_dm = leaves_b[2].double().mean().item()
+    assert abs(ne.item() - ref_ne) <= 2e-7 * max(1.0, abs(ref_ne)) and abs(ne.item() - ne_t.item()) <= 2e-5
+    assert abs(dm.item() - ref_dm) <= 2e-7 * max(1.0, abs(ref_dm)) and abs(dm.item() - dm_t.item()) <= 2e-5
+    for a, b in zip(leaves_a, leaves_b):
+        assert a.grad.shape == b.grad.shape
+        assert (a.grad - b.grad).abs().max() <= 3e-7 * b.grad.abs().max()
+    # bit-reproducible
+    ne2, dm2 = geometry_regularizers(rn, sn, rd)
+    assert ne2.item() == ne.item() and dm2.item() == dm.item()

@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from g4splat_amd import _lib, synthetic  # noqa: E402
 from g4splat_amd.gaussian_model import GaussianModel  # noqa: E402
 from g4splat_amd.gaussian_renderer import render  # noqa: E402
-from g4splat_amd.losses import photometric_loss  # noqa: E402
+from g4splat_amd.losses import geometry_regularizers, photometric_loss  # noqa: E402
 
 
 def main():
@@ -56,8 +56,8 @@ def main():
     def iteration(i):
         out = render(cams[i % 8], model, pipe, bg)
         loss, _l1, _s = photometric_loss(out["render"], gts[i % 8], 0.2)
-        normal_error = (1 - (out["rend_normal"] * out["surf_normal"]).sum(dim=0))[None]
-        total = loss + 0.05 * normal_error.mean() + 100.0 * out["rend_dist"].mean()
+        normal_mean, dist_mean = geometry_regularizers(out["rend_normal"], out["surf_normal"], out["rend_dist"])
+        total = loss + 0.05 * normal_mean + 100.0 * dist_mean
         total.backward()
         with torch.no_grad():
             model.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
