@@ -185,6 +185,42 @@ def test_backward_is_deterministic(hip_lib):
         np.testing.assert_array_equal(a["grads"][k], b["grads"][k])
 
 
+def test_two_host_threads_on_their_own_streams(hip_lib):
+    """The library is re-entrant ("re-entrant across >= 2 host threads"): two threads, each on its
+    own HIP stream, run different scenes forward + backward concurrently several times; every result equals the one
+    computed alone on the default stream, bit for bit."""
+    import threading
+    import torch
+    jobs = [(scene_inputs(P=40000, W=320, H=240, seed=61, D=3, scale_mul=0.8), cotangents(240, 320, seed=2)),
+            (scene_inputs(P=25000, W=256, H=256, seed=62, D=1, bg=(0.3, 0.2, 0.1)), cotangents(256, 256, seed=3))]
+    alone = [run_hip(inp, g) for inp, g in jobs]
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream(device="cuda:0")
+            with torch.cuda.stream(stream):
+                for _ in range(6):
+                    results[i] = run_hip(*jobs[i])
+            stream.synchronize()
+        except Exception as ex:  # surfaced in the main thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(alone, results):
+        assert a["R"] == b["R"]
+        np.testing.assert_array_equal(a["color"], b["color"])
+        np.testing.assert_array_equal(a["others"], b["others"])
+        np.testing.assert_array_equal(a["radii"], b["radii"])
+        for k in a["grads"]:
+            np.testing.assert_array_equal(a["grads"][k], b["grads"][k])
+
+
 def test_backward_out_views_of_a_bucket(hip_lib):
     """`out=`: gradients written straight into views of one flat buffer (the all-reduce bucket of
     parallel.py) are bit-identical to the separately allocated ones; bad views are refused."""
