@@ -60,6 +60,42 @@ def test_version_and_error_strings(hip_lib):
     assert b"bad layout" in hip_lib.g4s_last_error()
 
 
+def test_argument_validation_is_host_side(hip_lib):
+    """Every entry point rejects bad arguments before it touches the device: negative status + a message, no launch."""
+    import ctypes
+    from g4splat_amd import _lib
+    lib = hip_lib
+    nul = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(256)  # never dereferenced: validation fails first
+    cb = _lib.RESIZE_FN(lambda ctx, n: 0)
+    INVALID = -1
+
+    def expect(rc, text):
+        assert rc == INVALID, rc
+        assert text.encode() in lib.g4s_last_error(), lib.g4s_last_error()
+
+    expect(lib.g4s_densify_stats(5, nul, one, nul, one, one, nul, nul), "NULL required pointer")
+    expect(lib.g4s_densify_stats(-1, one, one, nul, one, one, nul, nul), "must not be negative")
+    expect(lib.g4s_densify_stats(5, one, one, nul, one, one, one, nul), "NULL required pointer")  # max_radii2D without radii
+    assert lib.g4s_densify_stats(0, nul, nul, nul, nul, nul, nul, nul) == 0
+    expect(lib.g4s_geometry_regularizers_forward(0, 4, one, one, one, one, one, 1 << 20, nul), "must be positive")
+    expect(lib.g4s_geometry_regularizers_forward(4, 4, one, nul, one, one, one, 1 << 20, nul), "NULL required pointer")
+    expect(lib.g4s_geometry_regularizers_forward(4, 4, one, one, one, one, one, 8, nul), "workspace too small")
+    expect(lib.g4s_geometry_regularizers_backward(4, 4, one, one, nul, one, one, one, nul), "NULL required pointer")
+    expect(lib.g4s_photometric_loss(0, 0, one, one, 0.2, one, nul, one, 1 << 20, nul), "must be positive")
+    expect(lib.g4s_adam_step(0, nul, nul, nul, nul, nul, nul, nul, 0.9, 0.999, 1e-15, nul), "1..8 segments")
+    # split SH: the dc tensor and, for M > 1, the rest tensor are required
+    fwd_tail = (one, one, 1.0, one, nul, one, one, one, 1.0, 1.0, 0, one, one, nul, 0, nul)
+    expect(lib.g4s_rasterizer_forward_split_sh(cb, nul, cb, nul, cb, nul, 10, 3, 16, one, 32, 32, one, nul, one, *fwd_tail),
+           "split SH needs")
+    expect(lib.g4s_rasterizer_forward_split_sh(cb, nul, cb, nul, cb, nul, 10, 3, 16, one, 32, 32, one, one, nul, *fwd_tail),
+           "split SH needs")
+    expect(lib.g4s_rasterizer_forward(_lib.RESIZE_FN(), nul, cb, nul, cb, nul, 10, 3, 16, one, 32, 32, one, one, nul, *fwd_tail),
+           "resize callbacks")
+    expect(lib.g4s_rasterizer_forward(cb, nul, cb, nul, cb, nul, 10, 3, 16, one, 0, 32, one, one, nul, *fwd_tail),
+           "must be positive")
+
+
 def _layout(lib, P, R, W, H):
     import ctypes
     from g4splat_amd import _lib
