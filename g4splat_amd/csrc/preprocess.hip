@@ -203,14 +203,24 @@ __device__ __forceinline__ bool lowpass_never_matters(const float* T, float cx, 
 // of the reference's GaussianModel, 2dgs/scene/gaussian_model.py:  get_features = cat(_features_dc, _features_rest)).
 __device__ __forceinline__ void load_sh(const float* __restrict__ shs, const float* __restrict__ rest, size_t idx, int M,
                                         int deg, bool vec16, float* sh /*48*/) {
-    const int n = 3 * (deg + 1) * (deg + 1);
+    const int n = 3 * (deg + 1) * (deg + 1);  // active floats (vec16 path)
     if (rest != nullptr) {
         const float* p0 = shs + idx * 3;
         const float* p1 = rest + idx * (size_t)(M - 1) * 3;
         sh[0] = p0[0]; sh[1] = p0[1]; sh[2] = p0[2];
+        // one unconditional run per SH band, so that the loads of a band merge into wide accesses
+        if (deg > 0) {
 #pragma unroll
-        for (int i = 3; i < 48; i++)
-            if (i < n) sh[i] = p1[i - 3];
+            for (int i = 3; i < 12; i++) sh[i] = p1[i - 3];
+            if (deg > 1) {
+#pragma unroll
+                for (int i = 12; i < 27; i++) sh[i] = p1[i - 3];
+                if (deg > 2) {
+#pragma unroll
+                    for (int i = 27; i < 48; i++) sh[i] = p1[i - 3];
+                }
+            }
+        }
     } else if (vec16) {
         const float4* p = reinterpret_cast<const float4*>(shs + idx * 48);
 #pragma unroll
@@ -222,9 +232,19 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, const flo
         }
     } else {
         const float* p = shs + idx * (size_t)M * 3;
+        sh[0] = p[0]; sh[1] = p[1]; sh[2] = p[2];
+        if (deg > 0) {
 #pragma unroll
-        for (int i = 0; i < 48; i++)
-            if (i < n) sh[i] = p[i];
+            for (int i = 3; i < 12; i++) sh[i] = p[i];
+            if (deg > 1) {
+#pragma unroll
+                for (int i = 12; i < 27; i++) sh[i] = p[i];
+                if (deg > 2) {
+#pragma unroll
+                    for (int i = 27; i < 48; i++) sh[i] = p[i];
+                }
+            }
+        }
     }
 }
 
@@ -271,6 +291,9 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, F3 pos, F3 c
 // K1: forward.cu:150-253.  Also seeds the depth sort (key = depth bits, CULLED_KEY if the
 // Gaussian emits nothing; payload = index), computes the conservative alpha-cutoff bounding
 // box (record quad 5) and accumulates the reference's instance count (num_rendered).
+// SH_MODE: 0 = packed [P,16,3] on a 16-byte aligned base (quad loads), 1 = packed generic, 2 = split (dc / rest).
+// One instantiation per layout: a runtime switch inside one kernel costs the common layout ~20 % (register copies at the joins).
+template <int SH_MODE>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
     const bool in_range = idx < a.P;
@@ -317,7 +340,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         float rgb[3];
                         if (a.colors_precomp == nullptr) {
                             float sh[48];
-                            load_sh(a.shs, a.shs_rest, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+                            load_sh(a.shs, SH_MODE == 2 ? a.shs_rest : nullptr, (size_t)idx, a.M, a.D, SH_MODE == 0, sh);
                             sh_to_rgb(a.D, sh, p, mk3(a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]), rgb, clamp_bits);
                         } else {
                             rgb[0] = a.colors_precomp[3 * (size_t)idx];
@@ -387,7 +410,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const dim3 grid((a.P + 255) / 256), block(256);
+    if (a.shs_rest != nullptr) hipLaunchKernelGGL(preprocess_fwd_kernel<2>, grid, block, 0, s, a);
+    else if (a.sh_vec16) hipLaunchKernelGGL(preprocess_fwd_kernel<0>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(preprocess_fwd_kernel<1>, grid, block, 0, s, a);
 }
 
 // K9: rasterizer_impl.cu:54-66
@@ -686,6 +712,7 @@ __global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) 
 
 // K8b: one thread per Gaussian; the folded terms arrive through LDS (coalesced load of the block's
 // 256 x 18 floats).
+template <int SH_MODE>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     __shared__ float s_sum[256 * K8_SUM_STRIDE];
     const int t = (int)threadIdx.x;
@@ -715,7 +742,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     float dT_out[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) dT_out[i] = g[6 + i];
-    const bool split_sh = a.shs_rest != nullptr;
+    constexpr bool split_sh = SH_MODE == 2;
     float* dsh = a.M > 0 ? a.dL_dsh + (size_t)idx * (split_sh ? 1 : a.M) * 3 : nullptr;
     float* dsh_rest = split_sh ? a.dL_dsh_rest + (size_t)idx * (a.M - 1) * 3 : nullptr;
 
@@ -815,9 +842,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         }
         if (a.shs != nullptr) {
             float sh[48];
-            load_sh(a.shs, a.shs_rest, (size_t)idx, a.M, a.D, a.sh_vec16, sh);
+            load_sh(a.shs, SH_MODE == 2 ? a.shs_rest : nullptr, (size_t)idx, a.M, a.D, SH_MODE == 0, sh);
             const F3 dm = sh_backward(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
-                                      mk3(a.campos[0], a.campos[1], a.campos[2]), a.clamped[idx], g, dsh, dsh_rest, a.sh_vec16);
+                                      mk3(a.campos[0], a.campos[1], a.campos[2]), a.clamped[idx], g, dsh, dsh_rest, SH_MODE == 0);
             dmean3[0] += dm.x;
             dmean3[1] += dm.y;
             dmean3[2] += dm.z;
@@ -844,7 +871,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     hipLaunchKernelGGL(fold_records_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const dim3 grid((a.P + 255) / 256), block(256);
+    if (a.shs_rest != nullptr) hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, 0, s, a);
+    else if (a.sh_vec16) hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, 0, s, a);
 }
 
 }  // namespace g4s
