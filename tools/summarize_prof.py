@@ -38,7 +38,7 @@ if len(sys.argv) >= 4:
              "tile_ranges_kernel": "tile_ranges"}
     kern = {}
     for k in agg:
-        key = names.get(k) or ("tile_sort" if k.startswith("radix_scatter_kernel<unsigned long") else None)
+        key = names.get(k) or names.get(k.split("<")[0]) or ("tile_sort" if k.startswith("radix_scatter_kernel<unsigned long") else None)
         if key and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
             kern[key] = {"FETCH_SIZE": round(agg[k]["FETCH_SIZE"] / max(cnt[k]["FETCH_SIZE"], 1), 1),
                          "WRITE_SIZE": round(agg[k]["WRITE_SIZE"] / max(cnt[k]["WRITE_SIZE"], 1), 1)}
