@@ -370,9 +370,9 @@ extern "C" int g4s_rasterizer_forward_split_sh(
 }
 
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
-    // gradient records | folded per-Gaussian sums | one validity byte per record
+    // gradient records | folded per-Gaussian sums | one validity byte per record | deep-tile counter + list
     return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + align_up((size_t)(P > 0 ? P : 1) * GRAD_FLOATS * 4) +
-           align_up((size_t)(R > 0 ? R : 1)) + 256;
+           align_up((size_t)(R > 0 ? R : 1)) + 256 + 65536 * 4 + 256;
 }
 
 static int rasterizer_backward_impl(
@@ -421,7 +421,10 @@ static int rasterizer_backward_impl(
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
     float* gsum = (float*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));
     uint8_t* rec_flag = (uint8_t*)gsum + align_up((size_t)P * GRAD_FLOATS * 4);
-    if (R > 0) HIP_TRY(hipMemsetAsync(rec_flag, 0, align_up((size_t)R), stream));
+    // the deep-tile counter sits right behind the validity bytes so that one memset clears both
+    uint32_t* hot_count = (uint32_t*)(rec_flag + align_up((size_t)(R > 0 ? R : 1)));
+    uint32_t* hot_list = hot_count + 64;
+    if (R > 0) HIP_TRY(hipMemsetAsync(rec_flag, 0, align_up((size_t)R) + 256, stream));
     if (R > 0) {
         char* bin = align_ptr(binning_buffer);
         const int tile_bits = (int)higher_msb((uint32_t)tiles);
@@ -437,6 +440,17 @@ static int rasterizer_backward_impl(
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
         bb.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
+        // One wave per tile is the efficient form when there are enough tiles to fill the GPU (1 024 SIMDs x 3
+        // waves); a small frame (<= 768 tiles, e.g. 256 x 256) runs about twice as fast with four waves per tile,
+        // and so does any single tile that is much deeper than the rest (measured: tools/deep_tile_bench.py).
+        // In a full-size frame only OUTLIERS are handed over -- tiles at least four times deeper than the average
+        // list (and deeper than 2 048): when every tile is deep (3 M surfels at 1200x680) one wave each stays the
+        // faster form, the four-wave kernel does ~1.9x the work per tile.
+        const long long avg_list = (long long)R / (tiles > 0 ? tiles : 1);
+        const long long outlier = 4 * avg_list > BWD_HOT_THRESHOLD ? 4 * avg_list : BWD_HOT_THRESHOLD;
+        bb.hot_threshold = getenv("G4S_BWD_HOT_THRESHOLD") ? atoi(getenv("G4S_BWD_HOT_THRESHOLD"))
+                           : (tiles <= BWD_FOUR_WAVE_MAX_TILES ? -1 : (int)(outlier < 0x7fffffff ? outlier : 0x7fffffff));
+        bb.hot_count = hot_count; bb.hot_list = hot_list;
         { ProfScope ps(PF_BLEND_BWD, stream); launch_blend_bwd(bb, stream); }
         CHECK_LAUNCH("blend_bwd");
     }

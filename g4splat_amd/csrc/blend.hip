@@ -304,6 +304,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int n_live = (int)wave_max_u32(max_last);
     // 1-based list position of the deepest median contributor of the tile: entries behind it skip the median term
     const uint32_t tile_max_median = wave_max_u32(max_median);
+    if (n_live > a.hot_threshold) {  // a deep tile would be this kernel's tail: four waves take it (blend_bwd_hot_kernel)
+        if (lane == 0) a.hot_list[atomicAdd(a.hot_count, 1u)] = (uint32_t)tile;
+        return;
+    }
     // (records of instances that receive no contribution are never written; rec_flag tells the fold which are)
 
     // batches from the back of the live range; lane t stages list position hi-1-t
@@ -454,8 +458,235 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// K7 backward for deep tiles: four waves per tile, one 8x8 quadrant (one pixel per lane) each.
+//
+// The one-wave kernel above is the efficient form (the lane's four pixels share one reduction per entry) but its
+// time per tile grows with the list: a tile whose last contributor sits at position 10^4 keeps a single wave busy
+// for milliseconds while the rest of the GPU idles.  Such tiles are collected in hot_list and handled here with
+// four times the lanes: every wave walks the same staged batch for its own quadrant (qhit bit), reduces its 64
+// pixels with the same permlane tree, and parks the partial sums in LDS; after the batch the four partials of an
+// entry are added in a fixed order (quadrant 0..3) and stored as the entry's gradient record.  Deterministic; the
+// sums are associated differently from the one-wave kernel's, so the two agree to rounding, not bit for bit.
+constexpr int HOT_PART = 20;  // floats per partial: 16 common terms, 2 low-pass terms, 2 unused
+
+__global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[BLEND_QUADS][BWD_BATCH];
+    __shared__ uint32_t s_slot[BWD_BATCH];
+    __shared__ uint32_t s_q[BWD_BATCH];      // bits 0..3 qhit, bit 4 = low-pass exponent never matters
+    __shared__ float s_part[4][BWD_BATCH][HOT_PART];
+    __shared__ unsigned long long s_lp[4];   // per wave: entries of the batch whose low-pass terms it wrote
+    __shared__ uint32_t s_max[2][4];
+
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const size_t N = (size_t)a.W * a.H;
+    // hot_threshold < 0: every tile of the frame is handled here, in tile_order (the one-wave kernel is not launched)
+    const bool all_tiles = a.hot_threshold < 0;
+    const uint32_t n_hot = all_tiles ? (uint32_t)(a.tiles_x * a.tiles_y) : *a.hot_count;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+    const float mscale = FAR_N / (FAR_N - NEAR_N);
+    const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
+    const bool row_writer = (lane & 15) == 15;
+    const int row = lane >> 4;
+
+    for (uint32_t h = blockIdx.x; h < n_hot; h += gridDim.x) {
+        const int tile = (int)(all_tiles ? a.tile_order[h] : a.hot_list[h]);
+        const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
+        const uint32_t r0 = a.ranges[2 * tile];
+        const int px = tile_x * TILE + (wv & 1) * 8 + (lane & 7), py = tile_y * TILE + (wv >> 1) * 8 + (lane >> 3);
+        const float pxf = (float)px, pyf = (float)py;
+        BwdPixel x{};
+        {
+            float T_final = 0, final_D = 0, final_D2 = 0, dL_dreg = 0;
+            if (px < a.W && py < a.H) {
+                const size_t pix_id = (size_t)a.W * py + px;
+                T_final = a.final_T[pix_id];
+                final_D = a.final_T[pix_id + N];
+                final_D2 = a.final_T[pix_id + 2 * N];
+                x.last_c = a.n_contrib[pix_id];
+                x.median_c = a.n_contrib[pix_id + N];
+                x.dpx0 = a.dL_dpix[pix_id];
+                x.dpx1 = a.dL_dpix[pix_id + N];
+                x.dpx2 = a.dL_dpix[pix_id + 2 * N];
+                x.dL_ddepth = a.dL_depths[pix_id + 0 * N];
+                x.dL_daccum = a.dL_depths[pix_id + 1 * N];
+                x.dn0 = a.dL_depths[pix_id + 2 * N];
+                x.dn1 = a.dL_depths[pix_id + 3 * N];
+                x.dn2 = a.dL_depths[pix_id + 4 * N];
+                x.dL_dmedian = a.dL_depths[pix_id + 5 * N];
+                dL_dreg = a.dL_depths[pix_id + 6 * N];
+            }
+            x.A2 = (1 - T_final) * dL_dreg;
+            x.D2 = 2.0f * final_D * dL_dreg;
+            x.C2 = final_D2 * dL_dreg;
+            x.nTfbg = -T_final * ((bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2);
+            x.T = T_final;
+        }
+        __syncthreads();  // the previous tile's last combine has read s_max / s_part
+        {
+            const uint32_t ml = wave_max_u32(x.last_c), mm = wave_max_u32(x.median_c);
+            if (lane == 0) { s_max[0][wv] = ml; s_max[1][wv] = mm; }
+        }
+        __syncthreads();
+        const int n_live = (int)max(max(s_max[0][0], s_max[0][1]), max(s_max[0][2], s_max[0][3]));
+        const uint32_t tile_max_median = max(max(s_max[1][0], s_max[1][1]), max(s_max[1][2], s_max[1][3]));
+
+        for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
+            const int m = imin_(BWD_BATCH, hi);
+            __syncthreads();  // the previous batch's combine is done with the LDS buffers
+            if (wv == 0) {    // wave 0 stages list positions hi-1 .. hi-m (lane t <-> position hi-1-t)
+                uint32_t qmask = 0;
+                if (lane < m) qmask = a.qhit[r0 + (uint32_t)(hi - 1 - lane)];
+                if (qmask != 0) {
+                    const uint64_t e = a.entries[r0 + (uint32_t)(hi - 1 - lane)];
+                    const float4* r = reinterpret_cast<const float4*>(a.rec) + (size_t)entry_idx(e) * REC_QUADS;
+                    float4 rq[BLEND_QUADS];
+#pragma unroll
+                    for (int i = 0; i < BLEND_QUADS; i++) rq[i] = r[i];
+                    if (!a.no_fastpath && (__float_as_uint(rq[0].w) & REC_NO_LOWPASS)) qmask |= 16u;
+#pragma unroll
+                    for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
+                    s_slot[lane] = __float_as_uint(rq[0].z) + entry_k(e);
+                }
+                s_q[lane] = qmask;
+            }
+            __syncthreads();
+
+            const uint32_t qbits = s_q[lane];
+            uint64_t todo = __ballot(((qbits >> wv) & 1u) != 0);
+            const uint64_t nolp_mask = __ballot((qbits & 16u) != 0);
+            uint64_t lp_mask = 0;  // wave-uniform
+            while (todo) {
+                const int j = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const bool nolp = (nolp_mask >> j) & 1ull;
+                const uint32_t pos = (uint32_t)(hi - 1 - j);
+                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
+                float g[18];
+#pragma unroll
+                for (int i = 0; i < 18; i++) g[i] = 0.0f;
+                bool lowpass = false;
+                PairEval e;
+                bool act = pos < x.last_c;
+                if (act) act = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                if (act) {  // the same arithmetic, in the same order, as the one-wave kernel's visit
+                    const float G = e.G, alpha = e.alpha, c_d = e.depth;
+                    const float inv1ma = fast_rcp(1.f - alpha);
+                    x.T = x.T * inv1ma;
+                    const float T = x.T;
+                    const float w = alpha * T;
+                    const float v = fmaf(q4.y, x.dpx0, fmaf(q4.z, x.dpx1, q4.w * x.dpx2)) +
+                                    fmaf(c_d, x.dL_ddepth, x.dL_daccum) +
+                                    fmaf(q1.x, x.dn0, fmaf(q1.y, x.dn1, q1.z * x.dn2));
+                    x.V_rec = fmaf(x.last_alpha, x.last_v - x.V_rec, x.V_rec);
+                    x.last_v = v;
+                    float dL_dalpha = v - x.V_rec;
+                    g[0] = w * x.dpx0; g[1] = w * x.dpx1; g[2] = w * x.dpx2;
+                    g[3] = w * x.dn0; g[4] = w * x.dn1; g[5] = w * x.dn2;
+                    const float inv_cd = fast_rcp(c_d);
+                    const float m_d = fmaf(-dmd_k, inv_cd, mscale);
+                    const float dmd_dd = dmd_k * inv_cd * inv_cd;
+                    float dL_dz = 0.0f;
+                    if (pos < tile_max_median) dL_dz = (pos + 1 == x.median_c) ? x.dL_dmedian : 0.0f;
+                    const float dL_dweight = fmaf(m_d, fmaf(m_d, x.A2, -x.D2), x.C2);
+                    const float dwt = dL_dweight - x.last_dL_dT;
+                    dL_dalpha += dwt;
+                    x.last_dL_dT = fmaf(alpha, dwt, x.last_dL_dT);
+                    const float dL_dmd = w * fmaf(m_d + m_d, x.A2, -x.D2);
+                    dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
+                    dL_dalpha *= T;
+                    x.last_alpha = alpha;
+                    dL_dalpha = fmaf(x.nTfbg, inv1ma, dL_dalpha);
+                    const float dL_dG = q1.w * dL_dalpha;
+                    dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
+                    if (e.in3d) {
+                        const float mG = dL_dG * -G;
+                        const float dL_dsx = fmaf(mG, e.sx, dL_dz * q3.z);
+                        const float dL_dsy = fmaf(mG, e.sy, dL_dz * q3.w);
+                        const float inv_pz = e.inv_pz;
+                        const float dpx_ = dL_dsx * inv_pz, dpy_ = dL_dsy * inv_pz;
+                        const float dpz_ = -fmaf(dpx_, e.sx, dpy_ * e.sy);
+                        const float dkx = fmaf(e.ly, dpz_, -(e.lz * dpy_)), dky = fmaf(e.lz, dpx_, -(e.lx * dpz_)),
+                                    dkz = fmaf(e.lx, dpy_, -(e.ly * dpx_));
+                        const float dlx = fmaf(dpy_, e.kz, -(dpz_ * e.ky)), dly = fmaf(dpz_, e.kx, -(dpx_ * e.kz)),
+                                    dlz = fmaf(dpx_, e.ky, -(dpy_ * e.kx));
+                        g[6] = -dkx; g[7] = -dky; g[8] = -dkz;
+                        g[9] = -dlx; g[10] = -dly; g[11] = -dlz;
+                        g[12] = fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
+                        g[13] = fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
+                        g[14] = fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
+                    } else {
+                        const float c2 = dL_dG * (-G * FILTER_INV_SQUARE);
+                        g[15] = c2 * e.dx;
+                        g[16] = c2 * e.dy;
+                        g[14] = dL_dz;
+                        lowpass = true;
+                    }
+                    g[17] = G * dL_dalpha;
+                }
+                float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],
+                               g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[17]};
+                float r[4];
+                wave_sum16_to_rows(t, r);
+                float* part = &s_part[wv][j][0];
+                if (row_writer) *reinterpret_cast<float4*>(part + 4 * row) = make_float4(r[0], r[1], r[2], r[3]);
+                if (__any(lowpass)) {
+                    const float r4 = wave_sum4_to_rows(g[15], g[16], 0.0f, 0.0f);
+                    if (row_writer && row < 2) part[16 + row] = r4;
+                    lp_mask |= 1ull << j;
+                }
+            }
+            if (lane == 0) s_lp[wv] = lp_mask;
+            __syncthreads();
+
+            // combine: entry e, quad c (five quads per record); partials added in quadrant order
+            for (int it = (int)threadIdx.x; it < BWD_BATCH * 5; it += 256) {
+                const int e = it / 5, c = it - 5 * e;
+                const uint32_t qm = s_q[e] & 15u;
+                if (qm == 0) continue;
+                const uint32_t slot = s_slot[e];
+                float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
+                if (c < 4) {
+                    float4 acc = make_float4(0, 0, 0, 0);
+                    bool first = true;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        if (!((qm >> w) & 1u)) continue;
+                        const float4 v = *reinterpret_cast<const float4*>(&s_part[w][e][4 * c]);
+                        if (first) { acc = v; first = false; }
+                        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+                    }
+                    *reinterpret_cast<float4*>(rec + 4 * c) = acc;
+                } else {
+                    float ax = 0.0f, ay = 0.0f;
+                    bool any_lp = false;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        if (((qm >> w) & 1u) && ((s_lp[w] >> e) & 1ull)) {
+                            ax = any_lp ? ax + s_part[w][e][16] : s_part[w][e][16];
+                            ay = any_lp ? ay + s_part[w][e][17] : s_part[w][e][17];
+                            any_lp = true;
+                        }
+                    }
+                    if (any_lp) { rec[16] = ax; rec[17] = ay; }
+                    a.rec_flag[slot] = any_lp ? 3 : 1;
+                }
+            }
+        }
+    }
+}
+
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.tiles_x * a.tiles_y), dim3(64), 0, s, a);
+    const int tiles = a.tiles_x * a.tiles_y;
+    // (up to four resident workgroups per CU; each loops over its share of the list)
+    const dim3 hot_grid(tiles < 1024 ? tiles : 1024);
+    if (a.hot_threshold < 0) {  // small frame: four waves per tile for all of them
+        hipLaunchKernelGGL(blend_bwd_hot_kernel, hot_grid, dim3(256), 0, s, a);
+        return;
+    }
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(tiles), dim3(64), 0, s, a);
+    // deep tiles the kernel above handed over (none in ordinary frames: the workgroups read hot_count and leave)
+    hipLaunchKernelGGL(blend_bwd_hot_kernel, hot_grid, dim3(256), 0, s, a);
 }
 
 }  // namespace g4s

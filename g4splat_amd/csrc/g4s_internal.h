@@ -202,7 +202,14 @@ struct BlendBwdArgs {
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
     uint8_t* rec_flag; // R bytes, pre-cleared: bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
     int no_fastpath;   // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
+    // deep tiles (more than hot_threshold live list positions) are left to blend_bwd_hot_kernel: the one-wave
+    // kernel appends them to hot_list (hot_count pre-cleared), the four-wave kernel runs behind it
+    int hot_threshold;  // < 0: all tiles go to the four-wave kernel (frames with too few tiles to fill the GPU one wave each)
+    uint32_t* hot_count;
+    uint32_t* hot_list;  // tiles entries
 };
+constexpr int BWD_HOT_THRESHOLD = 2048;  // live list positions; override for tests: G4S_BWD_HOT_THRESHOLD
+constexpr int BWD_FOUR_WAVE_MAX_TILES = 768;  // frames with at most this many tiles use the four-wave kernel throughout
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 
 struct PreprocessBwdArgs {

@@ -440,3 +440,93 @@ def test_hot_tiles(hip_lib, oracle_mod):
     assert n.max() > 5000
     check_forward(h, o)
     check_grads(h, o)
+
+
+def test_deep_tile_backward_matches_the_one_wave_backward(hip_lib, oracle_mod):
+    """Tiles deeper than G4S_BWD_HOT_THRESHOLD live list positions go through the four-wave backward
+    (blend_bwd_hot_kernel).  With the threshold at 0 (every tile) and at 40 (a mix of both kernels in one launch) the
+    gradients must equal the one-wave kernel's to rounding -- the partial sums are associated differently --, be
+    bit-reproducible, and pass the oracle bar; random small scenes, and the metric-size scene against the default."""
+    import os
+    import time
+    import torch
+    from g4splat_amd import synthetic
+
+    def grads_with(inp, g, threshold):
+        if threshold is not None:
+            os.environ["G4S_BWD_HOT_THRESHOLD"] = str(threshold)
+        try:
+            return run_hip(inp, g)
+        finally:
+            os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
+
+    for seed in range(40):
+        rng = np.random.default_rng(900 + seed)
+        inp = scene_inputs(P=int(rng.choice([200, 3000, 9000])), W=int(rng.choice([64, 177, 320])),
+                           H=int(rng.choice([48, 130, 200])), seed=900 + seed, D=int(rng.integers(0, 4)),
+                           scale_mul=float(rng.choice([0.05, 0.5, 1.0, 4.0])), opacity_max=float(rng.choice([0.05, 0.5, 1.0])),
+                           fov_deg=float(rng.uniform(40, 110)))
+        g = cotangents(inp["H"], inp["W"], seed=seed)
+        base = grads_with(inp, g, 1 << 30)  # one-wave kernel for every tile
+        for thr in (0, 40, -1):  # all tiles via the list / a mix / all tiles without the one-wave kernel
+            hot = grads_with(inp, g, thr)
+            again = grads_with(inp, g, thr)
+            for k in base["grads"]:
+                a, b = base["grads"][k], hot["grads"][k]
+                np.testing.assert_array_equal(hot["grads"][k], again["grads"][k])
+                if a.size:
+                    assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-30), (seed, thr, k)
+        if seed < 6:
+            o = run_oracle(oracle_mod, inp, g)
+            check_grads(grads_with(inp, g, 0), o)
+    # metric size: all 7 500 tiles through the four-wave kernel
+    P, W, H = 1_500_000, 1600, 1200
+    scene = synthetic.scene_room(P, seed=0)
+    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[2]
+    inp = dict(bg=np.zeros(3, np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
+               scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
+               view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+               H=H, W=W, sh=scene.shs, D=3, campos=cam.camera_center)
+    g = cotangents(H, W, seed=3)
+    base = grads_with(inp, g, None)
+    for thr in (0, -1):
+        hot = grads_with(inp, g, thr)
+        for k in base["grads"]:
+            a, b = base["grads"][k], hot["grads"][k]
+            assert np.abs(a - b).max() <= 1e-4 * np.abs(a).max(), (thr, k)
+
+
+def test_outlier_tiles_in_a_full_frame(hip_lib, oracle_mod):
+    """A 1 200-tile frame whose work is ordinary except for a translucent cluster that makes a few tiles several
+    thousand entries deep: those tiles (and only those) take the four-wave backward under the default policy."""
+    import os
+    base = scene_inputs(P=20000, W=640, H=480, seed=31, D=2, scale_mul=0.5)
+    rng = np.random.default_rng(32)
+    n = 40000
+    cam_z = 3.0
+    cluster = dict(means3D=np.stack([rng.normal(0.1, 0.02, n), rng.normal(-0.05, 0.02, n), rng.uniform(cam_z, cam_z + 1.0, n)], 1),
+                   opacity=np.full((n, 1), 0.004), scales=np.full((n, 2), 0.03),
+                   rotations=np.tile(np.array([[1.0, 0, 0, 0]]), (n, 1)), sh=rng.normal(0, 0.2, (n, 16, 3)))
+    inp = dict(base)
+    for k, v in cluster.items():
+        inp[k] = np.concatenate([base[k], v.astype(np.float32)], 0)
+    g = cotangents(480, 640, seed=4)
+    h = run_hip(inp, g)
+    st = hip_state(h, inp)
+    last = st["n_contrib"][0].reshape(480, 640)
+    deep = last.reshape(30, 16, 40, 16).max(axis=(1, 3))
+    assert (deep > 2048).sum() >= 2 and (deep > 2048).sum() < 60, (deep > 2048).sum()  # a few outlier tiles
+    os.environ["G4S_BWD_HOT_THRESHOLD"] = str(1 << 30)
+    try:
+        one_wave = run_hip(inp, g)
+    finally:
+        os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
+    differs = False
+    for k in h["grads"]:
+        a, b = one_wave["grads"][k], h["grads"][k]
+        assert np.abs(a - b).max() <= 5e-5 * max(np.abs(a).max(), 1e-30), k
+        differs = differs or not np.array_equal(a, b)
+    assert differs  # i.e. the four-wave kernel really ran (its sums are associated differently)
+    o = run_oracle(oracle_mod, inp, g)
+    check_forward(h, o)
+    check_grads(h, o)
