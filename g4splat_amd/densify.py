@@ -31,6 +31,8 @@ class DensifyMixin:
         """keep: bool[P] or None; append: dict group-name -> new rows or None.  Returns nothing; rebinds the six
         parameters (gaussian_model.py:495-560: replace_tensor_to_optimizer / _prune_optimizer /
         cat_tensors_to_optimizer)."""
+        # one mask -> index conversion (and one host sync) for all eighteen tensors instead of one per tensor
+        keep_idx = torch.nonzero(keep).squeeze(1) if keep is not None else None
         for group in self.optimizer.param_groups:
             assert len(group["params"]) == 1
             old = group["params"][0]
@@ -40,7 +42,7 @@ class DensifyMixin:
             state = self.optimizer.state.pop(old, None)
             data = old.detach()
             if keep is not None:
-                data = data[keep]
+                data = data.index_select(0, keep_idx)
             extra = append[name] if append is not None else None
             if extra is not None:
                 data = torch.cat((data, extra.detach()), dim=0)
@@ -49,7 +51,7 @@ class DensifyMixin:
                 for key in ("exp_avg", "exp_avg_sq"):
                     m = state[key]
                     if keep is not None:
-                        m = m[keep]
+                        m = m.index_select(0, keep_idx)
                     if extra is not None:
                         m = torch.cat((m, torch.zeros_like(extra)), dim=0)
                     state[key] = torch.zeros_like(new) if zero_moments else m.contiguous()
@@ -93,11 +95,12 @@ class DensifyMixin:
         """:527-541: drop the rows where `mask` is True, everywhere (parameters, moments, statistics)."""
         keep = ~mask
         self._edit_rows(keep=keep)
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
+        keep_idx = torch.nonzero(keep).squeeze(1)
+        self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, keep_idx)
+        self.denom = self.denom.index_select(0, keep_idx)
+        self.max_radii2D = self.max_radii2D.index_select(0, keep_idx)
         if self.mip_filter is not None and self.mip_filter.shape[0] == keep.shape[0]:
-            self.mip_filter = self.mip_filter[keep]
+            self.mip_filter = self.mip_filter.index_select(0, keep_idx)
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation):
         """:562-581: append rows; the densification statistics restart from zero for everybody."""
@@ -112,8 +115,10 @@ class DensifyMixin:
         """:612-626: small Gaussians with a large screen-space gradient are duplicated in place."""
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
               (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
-        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
-                                   self._scaling[sel], self._rotation[sel])
+        i = torch.nonzero(sel).squeeze(1)
+        pick = lambda t: t.index_select(0, i)
+        self.densification_postfix(pick(self._xyz), pick(self._features_dc), pick(self._features_rest), pick(self._opacity),
+                                   pick(self._scaling), pick(self._rotation))
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
         """:583-610: large Gaussians with a large gradient are replaced by N children sampled inside them (in the
@@ -122,15 +127,17 @@ class DensifyMixin:
         padded = torch.zeros((P,), device=self._xyz.device)
         padded[:grads.shape[0]] = grads.squeeze(-1) if grads.ndim > 1 else grads
         sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
-        s = self.get_scaling[sel].repeat(N, 1)
+        i = torch.nonzero(sel).squeeze(1)
+        pick = lambda t: t.index_select(0, i)
+        s = pick(self.get_scaling).repeat(N, 1)
         stds = torch.cat([s, torch.zeros_like(s[:, :1])], dim=-1)
         samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
-        R = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
-        new_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + self._xyz[sel].repeat(N, 1)
+        R = build_rotation(pick(self._rotation)).repeat(N, 1, 1)
+        new_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + pick(self._xyz).repeat(N, 1)
         new_scaling = torch.log(s / (0.8 * N))
-        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1),
-                                   self._opacity[sel].repeat(N, 1), new_scaling, self._rotation[sel].repeat(N, 1))
-        gone = torch.cat((sel, torch.zeros(N * int(sel.sum()), dtype=torch.bool, device=sel.device)))
+        self.densification_postfix(new_xyz, pick(self._features_dc).repeat(N, 1, 1), pick(self._features_rest).repeat(N, 1, 1),
+                                   pick(self._opacity).repeat(N, 1), new_scaling, pick(self._rotation).repeat(N, 1))
+        gone = torch.cat((sel, torch.zeros(N * int(i.numel()), dtype=torch.bool, device=sel.device)))
         self.prune_points(gone)
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
