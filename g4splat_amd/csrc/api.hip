@@ -329,6 +329,7 @@ static int rasterizer_forward_impl(
     CHECK_LAUNCH("tile order");
     BlendFwdArgs ba{};
     ba.W = width; ba.H = height; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y;
+    ba.tile_depth = (uint32_t*)(img + IL.tile_depth);
     ba.ranges = ranges; ba.tile_order = tile_order; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
     ba.qhit = qhit_ptr;
@@ -432,7 +433,10 @@ static int rasterizer_backward_impl(
         BlendBwdArgs bb{};
         bb.W = width; bb.H = height; bb.tiles_x = tiles_x; bb.tiles_y = tiles_y;
         bb.ranges = (const uint32_t*)(img + IL.ranges);
-        bb.tile_order = (const uint32_t*)(img + IL.tile_order);
+        // backward order: most blended (entry, quadrant) pairs first -- the forward counted them per tile
+        uint32_t* tile_order_bwd = (uint32_t*)(img + IL.tile_order_bwd);
+        launch_tile_order(tiles, (const uint32_t*)(img + IL.tile_depth), tile_order_bwd, stream);
+        bb.tile_order = getenv("G4S_BWD_FWD_ORDER") ? (const uint32_t*)(img + IL.tile_order) : tile_order_bwd;
         bb.entries = (const uint64_t*)(bin + ((passes & 1) ? BL.ent_b : BL.ent_a));
         bb.rec = rec; bb.bg = background;
         bb.final_T = (const float*)(img + IL.final_T);

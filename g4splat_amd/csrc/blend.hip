@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
     FwdPixel st{};
     st.Tt = inside ? 1.0f : 0.0f;
     st.T_done = 1.0f;
+    uint32_t n_blended = 0;  // wave-uniform: (entry, this quadrant) pairs some pixel blended = the backward's visits
 
     for (int b0 = 0; b0 < n; b0 += FWD_BATCH) {
         // end if the entire tile is saturated (forward.cu:327)
@@ -188,6 +189,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
                 if (!live) break;
             }
             if (lane == 0 && hit) s_hit[g0 >> 6][wv] = hit;
+            n_blended += (uint32_t)__builtin_popcountll(hit);
             if (!live) break;
         }
         }
@@ -199,6 +201,15 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendFwdArgs a) {
                                  ((uint32_t)((s_hit[g][2] >> b) & 1ull) << 2) | ((uint32_t)((s_hit[g][3] >> b) & 1ull) << 3);
             if (nib) a.qhit[r0 + b0 + threadIdx.x] = (uint8_t)nib;
         }
+    }
+    // the backward's work in this tile, for its longest-first ordering (tile_order_kernel reads (start, end) pairs)
+    __syncthreads();
+    if (lane == 0) (&s_hit[0][0])[wv] = n_blended;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long* v = &s_hit[0][0];
+        a.tile_depth[2 * tile] = 0u;
+        a.tile_depth[2 * tile + 1] = (uint32_t)((v[0] + v[1]) + (v[2] + v[3]));
     }
     const float T = st.Tt != 0.0f ? st.Tt : st.T_done;
     if (inside) {

@@ -59,7 +59,7 @@ struct BinLayout {
     int nchunks;
 };
 struct ImgLayout {
-    size_t ranges, final_T, n_contrib, tile_order, bytes;
+    size_t ranges, final_T, n_contrib, tile_order, tile_depth, tile_order_bwd, bytes;
 };
 
 inline GeomLayout geom_layout(size_t P) {
@@ -111,6 +111,8 @@ inline ImgLayout img_layout(size_t N, size_t tiles) {
     L.final_T = take(N * 3 * 4);
     L.n_contrib = take(N * 2 * 4);
     L.tile_order = take(tiles * 4);
+    L.tile_depth = take(tiles * 8);      // (0, deepest last contributor) per tile, written by the blend forward
+    L.tile_order_bwd = take(tiles * 4);  // processing order of the backward: deepest live list first
     L.bytes = o + 256;
     return L;
 }
@@ -180,6 +182,7 @@ struct BlendFwdArgs {
     float* final_T;
     uint32_t* n_contrib;
     uint8_t* qhit;  // per sorted instance: bit q set if some pixel of quadrant q blended it (pre-zeroed)
+    uint32_t* tile_depth;  // per tile (0, number of (entry, quadrant) pairs blended): the backward's work, for its ordering
     int box_only;   // experiments / tests (G4S_BOX_ONLY): skip quadrants by the bounding box only
     int no_fastpath;  // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
     float* out_color;
