@@ -361,7 +361,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
             float g[GRAD_STRIDE];
 #pragma unroll
-            for (int i = 0; i < GRAD_STRIDE; i++) g[i] = 0.0f;
+            for (int i = 0; i < 18; i++) {
+                g[i] = 0.0f;
+                // pin the zero here: left alone, the compiler sinks the initialisation into both arms of the first
+                // quadrant's branch and joins them with a 16-deep v_mov_b64 copy chain (33 moves instead of 18)
+                asm volatile("" : "+v"(g[i]));
+            }
             bool lowpass = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
