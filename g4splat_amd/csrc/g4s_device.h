@@ -70,6 +70,7 @@ __device__ __forceinline__ float wave_sum4_to_rows(float v0, float v1, float v2,
     r += dpp_f32<0x4E>(r);                 // quad_perm:[2,3,0,1]
     r += dpp_f32<0x124>(r);                // row_ror:4
     r += dpp_f32<0x128>(r);                // row_ror:8
+    asm volatile("" : "+v"(r));            // (see wave_sum16_to_rows)
     return r;
 }
 
@@ -106,6 +107,9 @@ __device__ __forceinline__ void wave_sum16_to_rows(float (&v)[16], float (&out)[
     r0 += dpp_f32<0x4E>(r0); r1 += dpp_f32<0x4E>(r1); r2 += dpp_f32<0x4E>(r2); r3 += dpp_f32<0x4E>(r3);
     r0 += dpp_f32<0x124>(r0); r1 += dpp_f32<0x124>(r1); r2 += dpp_f32<0x124>(r2); r3 += dpp_f32<0x124>(r3);
     r0 += dpp_f32<0x128>(r0); r1 += dpp_f32<0x128>(r1); r2 += dpp_f32<0x128>(r2); r3 += dpp_f32<0x128>(r3);
+    // keep the last additions here: sunk into the caller's `if (row_writer)` they can no longer be fused with their
+    // DPP operand (the rotate must see all lanes) and cost three instructions each instead of one
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
     // row k now holds the sums of v[4k] (r0), v[4k+1] (r1), v[4k+2] (r2), v[4k+3] (r3)
     out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
 }
