@@ -580,7 +580,10 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
                 float g[18];
 #pragma unroll
-                for (int i = 0; i < 18; i++) g[i] = 0.0f;
+                for (int i = 0; i < 18; i++) {
+                    g[i] = 0.0f;
+                    asm volatile("" : "+v"(g[i]));  // pinned, and accumulated into below (see the one-wave kernel)
+                }
                 bool lowpass = false;
                 PairEval e;
                 bool act = pos < x.last_c;
@@ -597,8 +600,8 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     x.V_rec = fmaf(x.last_alpha, x.last_v - x.V_rec, x.V_rec);
                     x.last_v = v;
                     float dL_dalpha = v - x.V_rec;
-                    g[0] = w * x.dpx0; g[1] = w * x.dpx1; g[2] = w * x.dpx2;
-                    g[3] = w * x.dn0; g[4] = w * x.dn1; g[5] = w * x.dn2;
+                    g[0] = fmaf(w, x.dpx0, g[0]); g[1] = fmaf(w, x.dpx1, g[1]); g[2] = fmaf(w, x.dpx2, g[2]);
+                    g[3] = fmaf(w, x.dn0, g[3]); g[4] = fmaf(w, x.dn1, g[4]); g[5] = fmaf(w, x.dn2, g[5]);
                     const float inv_cd = fast_rcp(c_d);
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
@@ -626,19 +629,19 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                                     dkz = fmaf(e.lx, dpy_, -(e.ly * dpx_));
                         const float dlx = fmaf(dpy_, e.kz, -(dpz_ * e.ky)), dly = fmaf(dpz_, e.kx, -(dpx_ * e.kz)),
                                     dlz = fmaf(dpx_, e.ky, -(dpy_ * e.kx));
-                        g[6] = -dkx; g[7] = -dky; g[8] = -dkz;
-                        g[9] = -dlx; g[10] = -dly; g[11] = -dlz;
-                        g[12] = fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
-                        g[13] = fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
-                        g[14] = fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
+                        g[6] -= dkx; g[7] -= dky; g[8] -= dkz;
+                        g[9] -= dlx; g[10] -= dly; g[11] -= dlz;
+                        g[12] += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
+                        g[13] += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
+                        g[14] += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
                     } else {
                         const float c2 = dL_dG * (-G * FILTER_INV_SQUARE);
-                        g[15] = c2 * e.dx;
-                        g[16] = c2 * e.dy;
-                        g[14] = dL_dz;
+                        g[15] = fmaf(c2, e.dx, g[15]);
+                        g[16] = fmaf(c2, e.dy, g[16]);
+                        g[14] += dL_dz;
                         lowpass = true;
                     }
-                    g[17] = G * dL_dalpha;
+                    g[17] = fmaf(G, dL_dalpha, g[17]);
                 }
                 float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],
                                g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[17]};
