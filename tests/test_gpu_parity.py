@@ -376,12 +376,14 @@ def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
             assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, (tag, name)
 
 
-@pytest.mark.parametrize("switch", ["G4S_BOX_ONLY", "G4S_NO_FASTPATH"])
+@pytest.mark.parametrize("switch", ["G4S_BOX_ONLY", "G4S_NO_FASTPATH", "G4S_BWD_FWD_ORDER"])
 def test_shortcuts_never_change_a_result(hip_lib, switch):
     """Two shortcuts of the blend kernels are pure work-savers and can be switched off from the environment:
       G4S_BOX_ONLY     the forward skips quadrants by the bounding box only, not by the exact cutoff ellipse;
       G4S_NO_FASTPATH  every splat takes the general per-pixel evaluation, also those whose record says that the
-                       low-pass exponent can never matter (REC_NO_LOWPASS).
+                       low-pass exponent can never matter (REC_NO_LOWPASS);
+      G4S_BWD_FWD_ORDER  the backward walks the tiles in the forward's order (by list length) instead of its own
+                       (by blended pairs) -- scheduling only.
     With either one off every output, the blend state and all gradients must be bit-identical -- on random small
     scenes (thin, huge, tiny, sub-pixel, translucent splats, wide fields of view) and at the metric's size."""
     import os
