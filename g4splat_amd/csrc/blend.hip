@@ -239,6 +239,7 @@ void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
 // K7 backward
 
 constexpr int BWD_BATCH = 64;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct BwdPixel {
     // constants.  The distortion terms only ever appear multiplied by dL_dreg, so they are kept as
@@ -359,13 +360,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             const bool nolp = (nolp_mask >> j) & 1ull;                               // scalar
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-            float g[GRAD_STRIDE];
+            // the 18 accumulators live in nine aligned register pairs so that they are zeroed with nine v_mov_b64;
+            // the zero is pinned here: left alone, the compiler sinks the initialisation into both arms of the first
+            // quadrant's branch and joins them with a 16-deep copy chain (33 moves)
+            v2f gp[9];
 #pragma unroll
-            for (int i = 0; i < 18; i++) {
-                g[i] = 0.0f;
-                // pin the zero here: left alone, the compiler sinks the initialisation into both arms of the first
-                // quadrant's branch and joins them with a 16-deep v_mov_b64 copy chain (33 moves instead of 18)
-                asm volatile("" : "+v"(g[i]));
+            for (int i = 0; i < 9; i++) {
+                gp[i] = v2f{0.0f, 0.0f};
+                asm volatile("" : "+v"(gp[i]));
             }
             bool lowpass = false;
 #pragma unroll
@@ -392,12 +394,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     x.V_rec = fmaf(x.last_alpha, x.last_v - x.V_rec, x.V_rec);  // a v + (1 - a) V_rec
                     x.last_v = v;
                     float dL_dalpha = v - x.V_rec;
-                    g[0] = fmaf(w, x.dpx0, g[0]);
-                    g[1] = fmaf(w, x.dpx1, g[1]);
-                    g[2] = fmaf(w, x.dpx2, g[2]);
-                    g[3] = fmaf(w, x.dn0, g[3]);
-                    g[4] = fmaf(w, x.dn1, g[4]);
-                    g[5] = fmaf(w, x.dn2, g[5]);
+                    gp[0].x = fmaf(w, x.dpx0, gp[0].x);
+                    gp[0].y = fmaf(w, x.dpx1, gp[0].y);
+                    gp[1].x = fmaf(w, x.dpx2, gp[1].x);
+                    gp[1].y = fmaf(w, x.dn0, gp[1].y);
+                    gp[2].x = fmaf(w, x.dn1, gp[2].x);
+                    gp[2].y = fmaf(w, x.dn2, gp[2].y);
 
                     const float inv_cd = fast_rcp(c_d);
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
@@ -429,23 +431,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                     dkz = fmaf(e.lx, dpy_, -(e.ly * dpx_));
                         const float dlx = fmaf(dpy_, e.kz, -(dpz_ * e.ky)), dly = fmaf(dpz_, e.kx, -(dpx_ * e.kz)),
                                     dlz = fmaf(dpx_, e.ky, -(dpy_ * e.kx));
-                        g[6] -= dkx;
-                        g[7] -= dky;
-                        g[8] -= dkz;
-                        g[9] -= dlx;
-                        g[10] -= dly;
-                        g[11] -= dlz;
-                        g[12] += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
-                        g[13] += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
-                        g[14] += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
+                        gp[3].x -= dkx;
+                        gp[3].y -= dky;
+                        gp[4].x -= dkz;
+                        gp[4].y -= dlx;
+                        gp[5].x -= dly;
+                        gp[5].y -= dlz;
+                        gp[6].x += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
+                        gp[6].y += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
+                        gp[7].x += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
                     } else {
                         const float c2 = dL_dG * (-G * FILTER_INV_SQUARE);
-                        g[15] = fmaf(c2, e.dx, g[15]);
-                        g[16] = fmaf(c2, e.dy, g[16]);
-                        g[14] += dL_dz;
+                        gp[7].y = fmaf(c2, e.dx, gp[7].y);
+                        gp[8].x = fmaf(c2, e.dy, gp[8].x);
+                        gp[7].x += dL_dz;
                         lowpass = true;
                     }
-                    g[17] = fmaf(G, dL_dalpha, g[17]);
+                    gp[8].y = fmaf(G, dL_dalpha, gp[8].y);
                 }
             }
             // 256 pixels -> 1: the four pixels of a lane were summed in registers above; the 64 lanes are
@@ -458,14 +460,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             {
                 const uint32_t slot = s_slot[j];
                 float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
-                float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],
-                               g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[17]};
+                float t[16] = {gp[0].x, gp[0].y, gp[1].x,  gp[1].y,  gp[2].x,  gp[2].y,  gp[3].x,  gp[3].y,
+                               gp[4].x, gp[4].y, gp[5].x, gp[5].y, gp[6].x, gp[6].y, gp[7].x, gp[8].y};
                 float r[4];
                 wave_sum16_to_rows(t, r);
                 if (row_writer) *reinterpret_cast<float4*>(rec + 4 * row) = make_float4(r[0], r[1], r[2], r[3]);
                 const bool lp = __any(lowpass);
                 if (lp) {
-                    const float r4 = wave_sum4_to_rows(g[15], g[16], 0.0f, 0.0f);
+                    const float r4 = wave_sum4_to_rows(gp[7].y, gp[8].x, 0.0f, 0.0f);
                     if (row_writer) rec[16 + row] = r4;
                 }
                 if (lane == 0) a.rec_flag[slot] = lp ? 3 : 1;
