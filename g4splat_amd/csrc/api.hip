@@ -643,6 +643,47 @@ extern "C" int g4s_densify_stats(int P, const float* grad_mean2D, const unsigned
     return G4S_OK;
 }
 
+extern "C" void g4s_activations_launch_internal(int fwd, int P, const float* scaling_or_scales, const float* rotation,
+                                                const float* opacity_or_opac, const float* g_scales, const float* g_rots,
+                                                const float* g_opac, float* out_s, float* out_r, float* out_o, hipStream_t s);
+
+extern "C" int g4s_activations_forward(int P, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                                       float* scales, float* rotations, float* opacities, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P must not be negative");
+    if (P == 0) return G4S_OK;
+    if (!scaling_raw || !rotation_raw || !opacity_raw || !scales || !rotations || !opacities)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (misaligned(scaling_raw, 8) || misaligned(scales, 8) || misaligned(rotation_raw, 16) || misaligned(rotations, 16))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "scaling / scales must be 8-byte, rotations 16-byte aligned");
+    g4s_activations_launch_internal(1, P, scaling_raw, rotation_raw, opacity_raw, nullptr, nullptr, nullptr, scales, rotations,
+                                    opacities, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(G4S_ERR_HIP, "activations launch: %s", hipGetErrorString(e));
+    return G4S_OK;
+}
+
+extern "C" int g4s_activations_backward(int P, const float* scales, const float* rotation_raw, const float* opacities,
+                                        const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                                        float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P must not be negative");
+    if (P == 0) return G4S_OK;
+    if (!scales || !rotation_raw || !opacities || !dL_dscales || !dL_drotations || !dL_dopacities || !dL_dscaling_raw ||
+        !dL_drotation_raw || !dL_dopacity_raw)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (misaligned(scales, 8) || misaligned(dL_dscales, 8) || misaligned(dL_dscaling_raw, 8) || misaligned(rotation_raw, 16) ||
+        misaligned(dL_drotations, 16) || misaligned(dL_drotation_raw, 16))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "scale tensors must be 8-byte, rotation tensors 16-byte aligned");
+    g4s_activations_launch_internal(0, P, scales, rotation_raw, opacities, dL_dscales, dL_drotations, dL_dopacities,
+                                    dL_dscaling_raw, dL_drotation_raw, dL_dopacity_raw, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(G4S_ERR_HIP, "activations backward launch: %s", hipGetErrorString(e));
+    return G4S_OK;
+}
+
 extern "C" void g4s_pack_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, const long long* idx, int n,
                                               float* packed, int unpack, hipStream_t s);
 

@@ -383,6 +383,64 @@ __global__ void __launch_bounds__(256) densify_stats_kernel(int P, const float* 
 }
 }  // namespace g4s
 
+// Activations of the Gaussian parameters as render() reads them (2dgs/scene/gaussian_model.py:157-192, without the
+// optional mip filter): scales = exp(_scaling), rotations = _rotation / max(|_rotation|, 1e-12), opacity =
+// sigmoid(_opacity) -- one pass instead of ~5 element-wise / reduction launches, and one pass for their backward
+// instead of ~9.
+namespace g4s {
+__global__ void __launch_bounds__(256) activations_fwd_kernel(int P, const float2* __restrict__ scaling,
+                                                              const float4* __restrict__ rotation,
+                                                              const float* __restrict__ opacity, float2* __restrict__ scales,
+                                                              float4* __restrict__ rots, float* __restrict__ opac) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= P) return;
+    const float2 s = scaling[i];
+    scales[i] = make_float2(expf(s.x), expf(s.y));
+    const float4 q = rotation[i];
+    const float n = fmaxf(sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w), 1e-12f);
+    rots[i] = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    opac[i] = 1.0f / (1.0f + expf(-opacity[i]));
+}
+
+__global__ void __launch_bounds__(256) activations_bwd_kernel(int P, const float2* __restrict__ scales,
+                                                              const float4* __restrict__ rotation,
+                                                              const float* __restrict__ opac, const float2* __restrict__ g_scales,
+                                                              const float4* __restrict__ g_rots, const float* __restrict__ g_opac,
+                                                              float2* __restrict__ d_scaling, float4* __restrict__ d_rotation,
+                                                              float* __restrict__ d_opacity) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= P) return;
+    const float2 y = scales[i], gs = g_scales[i];
+    d_scaling[i] = make_float2(gs.x * y.x, gs.y * y.y);  // exp' = exp
+    const float4 q = rotation[i], g = g_rots[i];
+    const float norm = sqrtf(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    if (norm > 1e-12f) {  // y = q / |q|:  dq = (g - y <y, g>) / |q|
+        const float inv = 1.0f / norm;
+        const float4 u = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        const float d = ((u.x * g.x + u.y * g.y) + u.z * g.z) + u.w * g.w;
+        d_rotation[i] = make_float4((g.x - u.x * d) * inv, (g.y - u.y * d) * inv, (g.z - u.z * d) * inv, (g.w - u.w * d) * inv);
+    } else {              // clamped denominator: y = q / 1e-12
+        d_rotation[i] = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+    }
+    const float o = opac[i];
+    d_opacity[i] = g_opac[i] * o * (1.0f - o);  // sigmoid' = y (1 - y)
+}
+}  // namespace g4s
+
+extern "C" void g4s_activations_launch_internal(int fwd, int P, const float* scaling_or_scales, const float* rotation,
+                                                const float* opacity_or_opac, const float* g_scales, const float* g_rots,
+                                                const float* g_opac, float* out_s, float* out_r, float* out_o, hipStream_t s) {
+    if (P <= 0) return;
+    const dim3 grid((unsigned)((P + 255) / 256)), block(256);
+    if (fwd)
+        hipLaunchKernelGGL(g4s::activations_fwd_kernel, grid, block, 0, s, P, (const float2*)scaling_or_scales, (const float4*)rotation,
+                           opacity_or_opac, (float2*)out_s, (float4*)out_r, out_o);
+    else
+        hipLaunchKernelGGL(g4s::activations_bwd_kernel, grid, block, 0, s, P, (const float2*)scaling_or_scales, (const float4*)rotation,
+                           opacity_or_opac, (const float2*)g_scales, (const float4*)g_rots, g_opac, (float2*)out_s, (float4*)out_r,
+                           out_o);
+}
+
 extern "C" void g4s_densify_stats_launch_internal(int P, const float* grad, const unsigned char* filter, const int* radii,
                                                   float* accum, float* denom, float* max_radii, hipStream_t s) {
     if (P <= 0) return;

@@ -80,6 +80,15 @@ class GaussianModel(DensifyMixin):
             o = o * torch.sqrt(s2.prod(dim=1) / (s2 + torch.square(self.mip_filter)).prod(dim=1))[..., None]
         return o
 
+    @property
+    def get_activated(self):
+        """(get_scaling, get_rotation, get_opacity) at once: one fused HIP launch each way on a HIP device with the mip
+        filter off (optim.fused_activations), the three getters otherwise.  render() reads this when present."""
+        if self._scaling.is_cuda and not self.use_mip_filter:
+            from .optim import fused_activations
+            return fused_activations(self._scaling, self._rotation, self._opacity)
+        return self.get_scaling, self.get_rotation, self.get_opacity
+
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1

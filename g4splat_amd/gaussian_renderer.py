@@ -37,7 +37,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
     rasterizer = (rasterizer_cls or GaussianRasterizer)(raster_settings=raster_settings)
 
-    scales = rotations = cov3D_precomp = None
+    scales = rotations = cov3D_precomp = opacity = None
     if getattr(pipe, "compute_cov3D_python", False):
         # python formulation of T (:64-75); columns [0,1,3] only, so the z row of ndc2pix is irrelevant
         splat2world = pc.get_covariance(scaling_modifier)
@@ -48,7 +48,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
         cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        # (the HIP model evaluates its three activations in one fused launch; the CPU checker path keeps the getters)
+        act = getattr(pc, "get_activated", None) if rasterizer_cls is None else None
+        if act is not None:
+            scales, rotations, opacity = act
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
 
     shs = colors_precomp = None
     if override_color is None:
@@ -61,7 +66,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         colors_precomp = override_color
 
     rendered_image, radii, allmap = rasterizer(means3D=xyz, means2D=screenspace_points, shs=shs,
-                                               colors_precomp=colors_precomp, opacities=pc.get_opacity, scales=scales,
+                                               colors_precomp=colors_precomp, opacities=pc.get_opacity if opacity is None else opacity, scales=scales,
                                                rotations=rotations, cov3D_precomp=cov3D_precomp)
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}

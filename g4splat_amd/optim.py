@@ -96,3 +96,54 @@ def densify_stats(grad_mean2D, update_filter, xyz_gradient_accum, denom, radii=N
                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"g4s_densify_stats failed ({rc}): {_lib.last_error()}")
+
+
+class _Activations(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling, rotation, opacity):
+        lib = _lib.load()
+        dev = scaling.device
+        P = int(scaling.shape[0])
+        s, r, o = scaling.detach().contiguous(), rotation.detach().contiguous(), opacity.detach().contiguous()
+        with torch.cuda.device(dev):
+            scales, rots, opac = torch.empty_like(s), torch.empty_like(r), torch.empty_like(o)
+            rc = lib.g4s_activations_forward(P, ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(r.data_ptr()),
+                                             ctypes.c_void_p(o.data_ptr()), ctypes.c_void_p(scales.data_ptr()),
+                                             ctypes.c_void_p(rots.data_ptr()), ctypes.c_void_p(opac.data_ptr()),
+                                             ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"g4s_activations_forward failed ({rc}): {_lib.last_error()}")
+        ctx.save_for_backward(scales, r, opac)
+        return scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_scales, g_rots, g_opac):
+        scales, r, opac = ctx.saved_tensors
+        lib = _lib.load()
+        dev = scales.device
+        P = int(scales.shape[0])
+        zero = lambda ref, g: torch.zeros_like(ref) if g is None else g.contiguous()
+        gs, gr, go = zero(scales, g_scales), zero(r, g_rots), zero(opac, g_opac)
+        with torch.cuda.device(dev):
+            ds, dr, do = torch.empty_like(scales), torch.empty_like(r), torch.empty_like(opac)
+            rc = lib.g4s_activations_backward(P, ctypes.c_void_p(scales.data_ptr()), ctypes.c_void_p(r.data_ptr()),
+                                              ctypes.c_void_p(opac.data_ptr()), ctypes.c_void_p(gs.data_ptr()),
+                                              ctypes.c_void_p(gr.data_ptr()), ctypes.c_void_p(go.data_ptr()),
+                                              ctypes.c_void_p(ds.data_ptr()), ctypes.c_void_p(dr.data_ptr()),
+                                              ctypes.c_void_p(do.data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"g4s_activations_backward failed ({rc}): {_lib.last_error()}")
+        return ds, dr, do
+
+
+def fused_activations(scaling, rotation, opacity):
+    """-> (exp(scaling) [P,2], normalize(rotation) [P,4], sigmoid(opacity) [P,1]): the three getters render() reads
+    (gaussian_model.py:157-192, mip filter off) as one HIP launch each way (include/g4s_optim.h).  HIP tensors only."""
+    if not (scaling.is_cuda and rotation.is_cuda and opacity.is_cuda):
+        raise RuntimeError("fused_activations: HIP tensors only")
+    P = scaling.shape[0]
+    if (tuple(scaling.shape) != (P, 2) or tuple(rotation.shape) != (P, 4) or opacity.numel() != P
+            or any(t.dtype != torch.float32 for t in (scaling, rotation, opacity))):
+        raise RuntimeError("fused_activations: expected float32 scaling [P,2], rotation [P,4], opacity [P,1]")
+    return _Activations.apply(scaling, rotation, opacity)

@@ -43,6 +43,19 @@ int g4s_adam_step(int nseg, float* const* params, const float* const* grads, flo
 int g4s_densify_stats(int P, const float* grad_mean2D, const unsigned char* update_filter, const int* radii,
                       float* xyz_gradient_accum, float* denom, float* max_radii2D, void* stream);
 
+/*
+ * Parameter activations as render() reads them (2d-gaussian-splatting/scene/gaussian_model.py:157-192, mip filter
+ * off): scales = exp(_scaling) [P,2], rotations = normalize(_rotation) [P,4] (x / max(|x|, 1e-12), as
+ * torch.nn.functional.normalize), opacities = sigmoid(_opacity) [P].  One launch each way instead of ~5 / ~9.
+ * The backward takes the activated scales / opacities the forward produced and the raw rotations.
+ * Scale tensors 8-byte, rotation tensors 16-byte aligned.
+ */
+int g4s_activations_forward(int P, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                            float* scales, float* rotations, float* opacities, void* stream);
+int g4s_activations_backward(int P, const float* scales, const float* rotation_raw, const float* opacities,
+                             const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                             float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

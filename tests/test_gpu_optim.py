@@ -146,3 +146,34 @@ def test_fused_densification_stats_match_the_torch_formulation(hip_lib):
     with pytest.raises(RuntimeError):
         densify_stats(torch.ones((P, 3), device=dev), torch.ones(P, dtype=torch.bool, device=dev), acc_d, den_d,
                       radii=torch.zeros(P, dtype=torch.int32, device=dev))
+
+
+def test_fused_activations_match_torch(hip_lib):
+    """g4s_activations_* against torch.exp / torch.nn.functional.normalize / torch.sigmoid and their autograd backward
+    (the getters of 2dgs/scene/gaussian_model.py:157-192, mip filter off)."""
+    from g4splat_amd.optim import fused_activations
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    P = 200_003
+    raw = [torch.randn((P, 2), generator=g) * 1.5 - 3.0, torch.randn((P, 4), generator=g), torch.randn((P, 1), generator=g) * 3]
+    raw[1][::1000] *= 1e-3  # nearly-degenerate quaternions
+    raw[1][5] = 0.0         # an exactly-zero quaternion takes the clamped branch
+    cot = [torch.randn(t.shape, generator=g) for t in raw]
+    a = [t.clone().to(dev).requires_grad_(True) for t in raw]
+    b = [t.clone().to(dev).requires_grad_(True) for t in raw]
+    ya = fused_activations(*a)
+    yb = (torch.exp(b[0]), torch.nn.functional.normalize(b[1]), torch.sigmoid(b[2]))
+    sum((y * c.to(dev)).sum() for y, c in zip(ya, cot)).backward()
+    sum((y * c.to(dev)).sum() for y, c in zip(yb, cot)).backward()
+    torch.cuda.synchronize()
+    for y, z in zip(ya, yb):
+        assert y.shape == z.shape
+        assert (y - z).detach().abs().max() <= 4e-7 * max(1.0, float(z.detach().abs().max()))
+    for x, z, name in zip(a, b, ("scaling", "rotation", "opacity")):
+        ref = z.grad
+        err = (x.grad - ref).abs()
+        tol = 2e-6 * ref.abs().clamp_min(1e-6) if name != "rotation" else 2e-5 * ref.abs().max(dim=1, keepdim=True).values.clamp_min(1e-6)
+        mask = torch.ones(P, dtype=torch.bool, device=dev)
+        mask[5] = False  # the zero quaternion: both give g / 1e-12, compare separately
+        assert bool((err[mask] <= tol[mask]).all()), name
+    assert torch.allclose(a[1].grad[5], b[1].grad[5], rtol=1e-5)
