@@ -54,6 +54,15 @@ def _call_guarded(fn, args, debug, dump_name, banner):
         raise
 
 
+def _present(grad_color, grad_depth, rs, device):
+    """An output the loss did not use has no cotangent (None): the native side wants both maps."""
+    if grad_color is None:
+        grad_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=device)
+    if grad_depth is None:
+        grad_depth = torch.zeros((7, rs.image_height, rs.image_width), dtype=torch.float32, device=device)
+    return grad_color, grad_depth
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -77,6 +86,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        grad_out_color, grad_depth = _present(grad_out_color, grad_depth, rs, means3D.device)
         bwd_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh,
                     rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
@@ -114,6 +124,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         rs = ctx.raster_settings
         (means3D, scales, rotations, cov3Ds_precomp, radii, sh_dc, sh_rest, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        grad_out_color, grad_depth = _present(grad_out_color, grad_depth, rs, means3D.device)
         empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
         (grad_means2D, _grad_colors, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _C.rasterize_gaussians_backward(

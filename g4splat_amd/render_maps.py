@@ -29,6 +29,9 @@ def _mat(t, dev):
 class _RenderMaps(torch.autograd.Function):
     @staticmethod
     def forward(ctx, allmap, world_view_transform, full_proj_transform, depth_ratio):
+        # maps the loss does not use arrive as None in backward (-> NULL for the library) instead of as zero-filled
+        # [.,H,W] tensors: five fills per training iteration less
+        ctx.set_materialize_grads(False)
         if not allmap.is_cuda:
             raise RuntimeError("allmap must be a CUDA tensor")
         if allmap.ndim != 3 or allmap.size(0) != 7:
