@@ -40,6 +40,18 @@ uint32_t* pinned_word() {
     return p;
 }
 
+// One event per host thread and device, recorded behind the read-back copy: the forward waits on it instead of on
+// the whole stream, so work queued after the copy keeps the GPU busy while the host reads the totals.
+hipEvent_t readback_event() {
+    thread_local hipEvent_t ev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ev[dev]) {
+        if (hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+    }
+    return ev[dev];
+}
+
 inline bool trace_on() {
     static const bool on = getenv("G4S_TRACE") != nullptr;
     return on;
@@ -261,8 +273,36 @@ static int rasterizer_forward_impl(
         CHECK_LAUNCH("scan totals");
         uint32_t* h_total = pinned_word();
         if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
+        hipEvent_t totals_ready = readback_event();
+        if (!totals_ready) return fail(G4S_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipMemcpyAsync(h_total, d_total, 12, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipEventRecord(totals_ready, stream));
+
+        // Queued BEFORE the host waits for the totals: nothing below needs them on the host -- the gradient slots do
+        // not depend on them, and the pack / depth sort / count of the emitting Gaussians read V (d_total[2]) on the
+        // device, their launches sized for P.  The GPU therefore has ~0.1 ms of work queued while the host reads the
+        // totals back, sizes the binning chunk and issues the rest: the read-back no longer drains the queue.
+        launch_grad_slots(P, tiles_touched, idx_block_offs, rec, GL.nblocks, stream);
+        CHECK_LAUNCH("grad slots");
+        const uint32_t* d_V = d_total + 2;
+        const uint32_t* gidx_sorted;
+        {   // depth order of the emitting Gaussians (stable => ties by ascending index): pack, then sort
+            ProfScope ps(PF_DEPTH_SORT, stream);
+            launch_compact_keys(P, tiles_touched, keys_a, vis_block_offs, keys_b, vals_b, GL.nblocks, stream);
+            const int cur = radix_sort_u32_pairs(keys_b, keys_a, vals_b, vals_a, P, (uint32_t*)(geom + GL.hist),
+                                                 (uint32_t*)(geom + GL.bin_total), stream, d_V);
+            gidx_sorted = cur ? vals_a : vals_b;
+        }
+        CHECK_LAUNCH("depth sort");
+        {
+            ProfScope ps(PF_COUNT_SCAN, stream);
+            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, block_sums, d_total + 4, GL.nblocks,
+                              stream, d_V);
+        }
+        CHECK_LAUNCH("count scan");
+
+        // the one host wait of the forward (rasterizer_impl.cu:281-282), on the read-back only
+        HIP_TRY(hipEventSynchronize(totals_ready));
         // h_total[0]: instances actually binned (3-sigma rect intersected with the alpha-cutoff box),
         // h_total[1]: the reference's count (3-sigma rect only) = the num_rendered this call returns,
         // h_total[2]: Gaussians that emit at least one instance.
@@ -271,27 +311,7 @@ static int rasterizer_forward_impl(
         R = (int)h_total[1];
         const int R_binned = (int)h_total[0];
         const int V_emit = (int)h_total[2];
-
-        launch_grad_slots(P, tiles_touched, idx_block_offs, rec, GL.nblocks, stream);
-        CHECK_LAUNCH("grad slots");
-
-        // depth order of the emitting Gaussians (stable => ties by ascending index): pack, then sort
-        const uint32_t* gidx_sorted = vals_b;
-        if (V_emit > 0) {
-            ProfScope ps(PF_DEPTH_SORT, stream);
-            launch_compact_keys(P, tiles_touched, keys_a, vis_block_offs, keys_b, vals_b, GL.nblocks, stream);
-            const int cur = radix_sort_u32_pairs(keys_b, keys_a, vals_b, vals_a, V_emit, (uint32_t*)(geom + GL.hist),
-                                                 (uint32_t*)(geom + GL.bin_total), stream);
-            gidx_sorted = cur ? vals_a : vals_b;
-        }
-        CHECK_LAUNCH("depth sort");
         const int nblocks_v = (V_emit + 255) / 256;
-        if (V_emit > 0) {
-            ProfScope ps(PF_COUNT_SCAN, stream);
-            launch_count_scan(V_emit, gidx_sorted, tiles_touched, block_sums, block_offs, block_sums, d_total + 4,
-                              nblocks_v, stream);
-        }
-        CHECK_LAUNCH("count scan");
 
         const BinLayout BL = bin_layout((size_t)R);
         char* bin = binning_buffer(binning_ctx, BL.bytes);

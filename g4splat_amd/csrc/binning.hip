@@ -23,9 +23,16 @@ namespace g4s {
 
 template <typename K>
 __global__ void __launch_bounds__(64) radix_hist_kernel(const K* __restrict__ keys, int n, int shift,
-                                                        uint32_t* __restrict__ hist, int nchunks, int chunk_len) {
+                                                        uint32_t* __restrict__ hist, int nchunks, int chunk_len,
+                                                        const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t h[256];
     const int chunk = (int)blockIdx.x;
+    if (d_n != nullptr) {  // the key count only lives on the device: the grid is sized for the largest possible n
+        n = (int)*d_n;
+        chunk_len = sort_chunk((size_t)n);
+        nchunks = sort_nchunks((size_t)n);
+        if (chunk >= nchunks) return;
+    }
     const int lane = (int)threadIdx.x;
     for (int i = lane; i < 256; i += 64) h[i] = 0;
     __syncthreads();
@@ -41,8 +48,10 @@ __global__ void __launch_bounds__(64) radix_hist_kernel(const K* __restrict__ ke
 
 // One block per digit row: exclusive scan of the row in place, row total to bin_total[row].
 __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ hist, int nchunks,
-                                                         uint32_t* __restrict__ bin_total) {
+                                                         uint32_t* __restrict__ bin_total,
+                                                         const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t sm4[4];
+    if (d_n != nullptr) nchunks = sort_nchunks((size_t)*d_n);
     uint32_t* row = hist + (size_t)blockIdx.x * nchunks;
     const int t = (int)threadIdx.x;
     const int seg = (nchunks + 255) / 256;
@@ -67,9 +76,15 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const K* __restrict__
                                                            uint32_t* __restrict__ vals_out, int n, int shift,
                                                            const uint32_t* __restrict__ hist,
                                                            const uint32_t* __restrict__ bin_total, int nchunks,
-                                                           int chunk_len) {
+                                                           int chunk_len, const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t offs[256];
     const int chunk = (int)blockIdx.x;
+    if (d_n != nullptr) {
+        n = (int)*d_n;
+        chunk_len = sort_chunk((size_t)n);
+        nchunks = sort_nchunks((size_t)n);
+        if (chunk >= nchunks) return;
+    }
     const int lane = (int)threadIdx.x;
     // global base of every digit = exclusive scan of bin totals + this chunk's row prefix
     {
@@ -124,25 +139,27 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const K* __restrict__
     }
 }
 
+// d_n == nullptr: n keys (host-known).  Otherwise n is read from *d_n by the kernels and only bounds the grid
+// (n_max >= *d_n): the launches can be queued before the host knows the count.
 template <typename K, bool HAS_VAL>
 static void radix_pass(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int n, int shift, uint32_t* hist,
-                       uint32_t* bin_total, hipStream_t s) {
-    const int chunk_len = sort_chunk((size_t)n), nchunks = sort_nchunks((size_t)n);
-    hipLaunchKernelGGL((radix_hist_kernel<K>), dim3(nchunks), dim3(64), 0, s, kin, n, shift, hist, nchunks, chunk_len);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, s, hist, nchunks, bin_total);
+                       uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr) {
+    const int chunk_len = sort_chunk((size_t)n), nchunks = d_n ? sort_nchunks_max((size_t)n) : sort_nchunks((size_t)n);
+    hipLaunchKernelGGL((radix_hist_kernel<K>), dim3(nchunks), dim3(64), 0, s, kin, n, shift, hist, nchunks, chunk_len, d_n);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(256), 0, s, hist, nchunks, bin_total, d_n);
     hipLaunchKernelGGL((radix_scatter_kernel<K, HAS_VAL>), dim3(nchunks), dim3(64), 0, s, kin, kout, vin, vout, n,
-                       shift, hist, bin_total, nchunks, chunk_len);
+                       shift, hist, bin_total, nchunks, chunk_len, d_n);
 }
 
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
-                         uint32_t* hist, uint32_t* bin_total, hipStream_t s) {
+                         uint32_t* hist, uint32_t* bin_total, hipStream_t s, const uint32_t* d_n) {
     if (n <= 0) return 0;
     int cur = 0;
     for (int shift = 0; shift < 32; shift += 8) {
         if (cur == 0)
-            radix_pass<uint32_t, true>(keys_a, keys_b, vals_a, vals_b, n, shift, hist, bin_total, s);
+            radix_pass<uint32_t, true>(keys_a, keys_b, vals_a, vals_b, n, shift, hist, bin_total, s, d_n);
         else
-            radix_pass<uint32_t, true>(keys_b, keys_a, vals_b, vals_a, n, shift, hist, bin_total, s);
+            radix_pass<uint32_t, true>(keys_b, keys_a, vals_b, vals_a, n, shift, hist, bin_total, s, d_n);
         cur ^= 1;
     }
     return cur;
@@ -168,8 +185,13 @@ int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_
 // tiles_touched gathered in depth order, 256 per block -> block sums.
 __global__ void __launch_bounds__(256) count_block_sums_kernel(int P, const uint32_t* __restrict__ gidx,
                                                                const uint32_t* __restrict__ tiles_touched,
-                                                               uint32_t* __restrict__ block_sums) {
+                                                               uint32_t* __restrict__ block_sums,
+                                                               const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t sm4[4];
+    if (d_n != nullptr) {  // device-side count: blocks past the end leave
+        P = (int)*d_n;
+        if ((int)(blockIdx.x * 256) >= P) return;
+    }
     const int r = (int)(blockIdx.x * 256 + threadIdx.x);
     uint32_t c = 0;
     if (r < P) c = tiles_touched[gidx[r]];
@@ -182,9 +204,11 @@ __global__ void __launch_bounds__(256) count_block_sums_kernel(int P, const uint
 __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, const uint32_t* __restrict__ block_sums,
                                                                uint32_t* __restrict__ block_offs,
                                                                const uint32_t* __restrict__ ref_block_sums,
-                                                               uint32_t* __restrict__ total) {
+                                                               uint32_t* __restrict__ total,
+                                                               const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t wsum[16], rsum[16];
     const int t = (int)threadIdx.x;
+    if (d_n != nullptr) nblocks = (int)((*d_n + 255u) / 256u);  // blocks of a device-side element count
     const int seg = (nblocks + 1023) / 1024;
     const int b = imin_(nblocks, t * seg), e = imin_(nblocks, b + seg);
     uint32_t sum = 0, ref = 0;
@@ -218,11 +242,12 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
 
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
                        uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
-                       hipStream_t s) {
+                       hipStream_t s, const uint32_t* d_n) {
+    // d_n != nullptr: P / nblocks only bound the grid, the kernels read the count from the device
     hipLaunchKernelGGL(count_block_sums_kernel, dim3(nblocks), dim3(256), 0, s, P, gidx_sorted, tiles_touched,
-                       block_sums);
+                       block_sums, d_n);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs,
-                       ref_block_sums, total);
+                       ref_block_sums, total, d_n);
 }
 
 // Load-balanced expansion: a block owns 256 consecutive depth ranks; its output range is
@@ -300,9 +325,9 @@ void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
                         hipStream_t s) {
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
-                       ref_block_sums, total);
+                       ref_block_sums, total, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, vis_block_sums, vis_block_offs,
-                       vis_block_sums, total + 2);
+                       vis_block_sums, total + 2, (const uint32_t*)nullptr);
 }
 
 // Only Gaussians that emit instances take part in the depth sort and in everything after it (typically a

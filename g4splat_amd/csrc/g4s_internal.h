@@ -27,14 +27,16 @@ constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 constexpr int SORT_CHUNK_MAX = 2048;  // keys per wave-private radix chunk (upper bound)
 // Chunk length for n keys: one wave per chunk; aim for ~8 waves per CU so that the per-wave serial
 // chain (chunk/64 steps) is short and the chip is full, within [256, 2048], a multiple of 64.
-inline int sort_chunk(size_t n) {
+__host__ __device__ inline int sort_chunk(size_t n) {
     size_t c = (n + 2047) / 2048;  // 256 CUs x 8 waves
     c = (c + 63) / 64 * 64;
     if (c < 256) c = 256;
     if (c > (size_t)SORT_CHUNK_MAX) c = SORT_CHUNK_MAX;
     return (int)c;
 }
-inline int sort_nchunks(size_t n) { return (int)((n + sort_chunk(n) - 1) / sort_chunk(n)); }
+__host__ __device__ inline int sort_nchunks(size_t n) { return (int)((n + sort_chunk(n) - 1) / sort_chunk(n)); }
+// upper bound of sort_nchunks(n) over all n <= n_max (grid size when n only lives on the device)
+inline int sort_nchunks_max(size_t n_max) { return (int)((n_max + 255) / 256 < 2112 ? (n_max + 255) / 256 + 1 : 2112); }
 // Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
 // <= 65536), 31..0 Gaussian index.  Every field sits on a natural 16/32-bit boundary on purpose:
 // hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load and then drops the mask.
@@ -77,7 +79,7 @@ inline GeomLayout geom_layout(size_t P) {
     L.vals_a = take(P * 4);
     L.vals_b = take(P * 4);
     // the depth sort runs over the emitting Gaussians only (n <= P): capacity for the finest chunking of any n <= P
-    L.hist = take((size_t)256 * (size_t)((P + 255) / 256 < 2112 ? (P + 255) / 256 + 1 : 2112) * 4);
+    L.hist = take((size_t)256 * (size_t)sort_nchunks_max(P) * 4);
     L.bin_total = take(256 * 4);
     L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
@@ -141,8 +143,9 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
 
 // Stable LSD radix sort.  32-bit keys with 32-bit payload (ping-pong a<->b, result index
 // returned: 0 = in *_a, 1 = in *_b) over bits [0,32).
+// d_n != nullptr: the count is read from *d_n on the device, `n` (>= *d_n) only sizes the launches.
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
-                         uint32_t* hist, uint32_t* bin_total, hipStream_t s);
+                         uint32_t* hist, uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr);
 // 64-bit keys-only over bits [begin_bit, end_bit).
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
                         uint32_t* bin_total, hipStream_t s);
@@ -151,7 +154,7 @@ int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_
 // total[0] = instances binned, total[1] = sum of ref_block_sums (the reference's num_rendered).
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
                        uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
-                       hipStream_t s);
+                       hipStream_t s, const uint32_t* d_n = nullptr);
 // Gradient-record slots in INDEX order: rec[idx].inst_off = exclusive scan of tiles_touched over idx
 // (so that the per-Gaussian fold of the backward streams the record buffer sequentially).
 void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec, int nblocks,
