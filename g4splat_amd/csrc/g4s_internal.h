@@ -36,7 +36,12 @@ __host__ __device__ inline int sort_chunk(size_t n) {
 }
 __host__ __device__ inline int sort_nchunks(size_t n) { return (int)((n + sort_chunk(n) - 1) / sort_chunk(n)); }
 // upper bound of sort_nchunks(n) over all n <= n_max (grid size when n only lives on the device)
-inline int sort_nchunks_max(size_t n_max) { return (int)((n_max + 255) / 256 < 2112 ? (n_max + 255) / 256 + 1 : 2112); }
+inline int sort_nchunks_max(size_t n_max) {
+    const size_t fine = (n_max + 255) / 256 + 1;             // chunks of 256 (small n)
+    const size_t coarse = (n_max + SORT_CHUNK_MAX - 1) / SORT_CHUNK_MAX + 1;  // chunks of 2048 (n > 4.2 M: the count grows again)
+    const size_t mid = fine < 2112 ? fine : 2112;            // in between the chunk length grows with n: <= 2048 + rounding
+    return (int)(mid > coarse ? mid : coarse);
+}
 // Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
 // <= 65536), 31..0 Gaussian index.  Every field sits on a natural 16/32-bit boundary on purpose:
 // hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load and then drops the mask.
