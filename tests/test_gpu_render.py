@@ -224,3 +224,41 @@ def test_split_sh_argument_errors(hip_lib):
     with pytest.raises(RuntimeError, match="split SH"):
         _C.rasterize_gaussians(z(3), z(10, 3), z(0), z(10, 1), z(10, 2), z(10, 4), 1.0, z(0), z(4, 4), z(4, 4), 1.0, 1.0,
                                32, 32, bad, 3, z(3), False, False)
+
+
+def test_more_than_four_million_emitting_gaussians(hip_lib):
+    """Above 4.3 M keys the depth sort's chunks stop growing (2 048 keys) and their number does instead: the
+    histogram capacity has to follow.  5.5 M small visible surfels, rendered twice with the Gaussians in a different
+    memory order: the depth sort makes the image independent of that order, bit for bit (all depths distinct)."""
+    from g4splat_amd.diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    P, W, H = 5_500_000, 512, 512
+    g = torch.Generator(device="cpu").manual_seed(77)
+    # distinct depths (random floats collide by the hundred thousand at this count, and ties resolve by index)
+    z = (1.0 + 8.0 * (torch.randperm(P, generator=g).double() + 0.5) / P).float()
+    assert torch.unique(z).numel() == P
+    xy = (torch.rand((P, 2), generator=g) - 0.5) * 1.1 * z[:, None]
+    means = torch.cat([xy, z[:, None]], 1)
+    scales = torch.full((P, 2), 0.004)
+    rots = torch.nn.functional.normalize(torch.randn((P, 4), generator=g))
+    opac = torch.rand((P, 1), generator=g) * 0.2 + 0.02
+    cols = torch.rand((P, 3), generator=g)
+    eye = torch.eye(4)
+    tan = 0.5774
+    proj = torch.tensor([[1 / tan, 0, 0, 0], [0, 1 / tan, 0, 0], [0, 0, 100.0 / 99.99, 1], [0, 0, -0.01 * 100.0 / 99.99, 0]])
+    e = torch.empty(0, device=dev)
+
+    def run(order):
+        t = lambda a: a[order].contiguous().to(dev)
+        out = _C.rasterize_gaussians(torch.zeros(3, device=dev), t(means), t(cols), t(opac), t(scales), t(rots), 1.0, e,
+                                     eye.to(dev), proj.to(dev), tan, tan, H, W, e, 0, torch.zeros(3, device=dev), False, False)
+        return out[0], out[1].cpu(), out[2].cpu(), out[3].cpu()
+
+    ident = torch.arange(P)
+    perm = torch.randperm(P, generator=g)
+    Ra, ca, oa, ra = run(ident)
+    Rb, cb, ob, rb = run(perm)
+    assert Ra == Rb and int((ra > 0).sum()) > 4_400_000
+    assert torch.equal(ra[perm], rb)
+    assert torch.equal(ca, cb) and torch.equal(oa, ob)
+    assert float(oa[1].max()) > 0.5  # the frame is really covered
