@@ -346,11 +346,15 @@ def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys):
         print("gradient rows beyond 1e-3 / relative L2 error:", rep)
 
 
+@pytest.mark.parametrize("backward", ["policy", "one-wave"])
 @pytest.mark.parametrize("block", range(20))
-def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
+def test_fuzz_small_scenes(hip_lib, oracle_mod, block, backward, monkeypatch):
     """Two hundred seeded random configurations (image sizes that are not multiples of the tile, 1-pixel-high images,
     huge and tiny splats, translucent and opaque, every SH degree, scale modifiers, backgrounds, fields of view)
-    against the oracle: outputs, radii, instance counts, culled tile lists, gradients."""
+    against the oracle: outputs, radii, instance counts, culled tile lists, gradients.  Frames this small take the
+    four-wave backward under the default policy; "one-wave" forces the one-wave-per-tile kernel on the same cases."""
+    if backward == "one-wave":
+        monkeypatch.setenv("G4S_BWD_HOT_THRESHOLD", str(1 << 30))
     for case in range(10):
         seed = 1000 + 10 * block + case
         rng = np.random.default_rng(seed)
