@@ -113,7 +113,7 @@ struct CutoffConic {
     double ex, ey, ux, uy, a2, b2;  // centre, unit major axis, squared semi-axes
 };
 // the conic  p.x^2 + p.y^2 - t p.z^2 <= 0  as an ellipse; false if it is not one (or is empty)
-__device__ bool cutoff_conic(const double* A, const double* B, const double* D, double t, CutoffConic& c) {
+__device__ bool cutoff_conic(const double* A, const double* B, const double* D, double t, CutoffConic& c, bool bound_error) {
     auto dotg = [t](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] - t * a[2] * b[2]; };
     const double aa = dotg(A, A), ab = dotg(A, B), bb = dotg(B, B), a0 = dotg(A, D), b0 = dotg(B, D), c0 = dotg(D, D);
     const double det = aa * bb - ab * ab;
@@ -122,6 +122,19 @@ __device__ bool cutoff_conic(const double* A, const double* B, const double* D, 
     c.ey = (b0 * aa - a0 * ab) / det;
     const double kappa = a0 * c.ex + b0 * c.ey - c0;  // -Q(e):  (x - e)^T H (x - e) <= kappa
     if (!(kappa > 0.0)) return false;
+    // kappa is a small difference of large terms and scales both semi-axes.  For needles with an aspect ratio in the
+    // thousands its rounding error in double precision reaches percents (found by tools/fuzz_sweep.py: a hair-thin
+    // splat whose long axis came out 1.3 % short and lost one contributing pixel).  A first-order error bound decides:
+    // the ellipse is only used where kappa is good to 1e-3, i.e. the axes to 5e-4, a quarter of their 0.2 % margin.
+    if (bound_error) {
+        const double u = 4.5e-16;  // two roundings per product / sum
+        const double nx = a0 * bb - b0 * ab, ny = b0 * aa - a0 * ab;
+        const double rel_det = u * (fabs(aa * bb) + fabs(ab * ab)) / det;
+        const double ex_err = fabs(c.ex) * (u * (fabs(a0 * bb) + fabs(b0 * ab)) / fmax(fabs(nx), 1e-300) + rel_det);
+        const double ey_err = fabs(c.ey) * (u * (fabs(b0 * aa) + fabs(a0 * ab)) / fmax(fabs(ny), 1e-300) + rel_det);
+        const double kappa_err = fabs(a0) * ex_err + fabs(b0) * ey_err + u * (fabs(a0 * c.ex) + fabs(b0 * c.ey) + fabs(c0));
+        if (!(kappa_err < 1e-3 * kappa)) return false;
+    }
     // eigen-decomposition of H = [aa ab; ab bb]: small eigenvalue <-> major axis
     const double tr = aa + bb, disc = sqrt(fmax((aa - bb) * (aa - bb) + 4.0 * ab * ab, 0.0));
     const double lmax = 0.5 * (tr + disc), lmin = det / lmax;  // (tr - disc) / 2 without the cancellation
@@ -160,7 +173,7 @@ __device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, 
     // conditioned: growing the cutoff by 1e-4 (ten times any rounding in the per-pixel evaluation) must move the
     // centre by less than a tenth of a pixel and the axes by less than 0.1 %; the larger of the two is used.
     CutoffConic c0, c1;
-    if (!cutoff_conic(A, B, D, t, c0) || !cutoff_conic(A, B, D, t * (1.0 + 1e-4), c1)) return;
+    if (!cutoff_conic(A, B, D, t, c0, false) || !cutoff_conic(A, B, D, t * (1.0 + 1e-4), c1, true)) return;
     const double shift2 = (c1.ex - c0.ex) * (c1.ex - c0.ex) + (c1.ey - c0.ey) * (c1.ey - c0.ey);
     if (!(shift2 < 0.01) || !(c1.a2 < c0.a2 * 1.002) || !(c1.b2 < c0.b2 * 1.002 + 1e-6) || !(c1.a2 >= c0.a2 * 0.999)) return;
     const double a2 = c1.a2 + 0.5625, b2 = c1.b2 + 0.5625;  // semi-axes^2 + 0.75^2
