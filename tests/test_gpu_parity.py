@@ -536,3 +536,26 @@ def test_outlier_tiles_in_a_full_frame(hip_lib, oracle_mod):
     o = run_oracle(oracle_mod, inp, g)
     check_forward(h, o)
     check_grads(h, o)
+
+
+def test_hair_thin_splat_found_by_the_fuzz_sweep(hip_lib, oracle_mod):
+    """tools/fuzz_sweep.py seed 50666: 20 000 splats of aspect ~2 800 : 1 with scale_modifier 1.6.  The cutoff conic of
+    one of them needs more than double precision (its kappa is a 1e-9 relative difference); before the error bound in
+    cutoff_conic its ellipse came out 1.3 % short and the forward culled a quadrant with one contributing pixel."""
+    seed = 50666
+    rng = np.random.default_rng(seed)
+    W = int(rng.choice([1, 7, 16, 33, 100, 161, 250, 400]))
+    H = int(rng.choice([1, 5, 16, 47, 96, 130, 300]))
+    P = int(rng.choice([1, 2, 17, 300, 2000, 6000, 20000]))
+    D = int(rng.integers(0, 4))
+    inp = scene_inputs(P=P, W=W, H=H, seed=seed, D=D, bg=tuple(rng.uniform(0, 1, 3)),
+                       scale_mul=float(rng.choice([0.02, 0.05, 0.5, 1.0, 4.0, 20.0])),
+                       opacity_max=float(rng.choice([0.02, 0.3, 1.0])),
+                       scale_modifier=float(rng.choice([1.0, 1.0, 0.7, 1.6])), fov_deg=float(rng.uniform(25, 115)))
+    assert (P, W, H) == (20000, 100, 130)
+    inp["scales"] = (inp["scales"] * np.array([[0.01, 40.0]], np.float32)).astype(np.float32)
+    g = cotangents(H, W, seed=seed)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    check_forward(h, o)
+    check_grads(h, o)
