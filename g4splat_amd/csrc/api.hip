@@ -107,6 +107,8 @@ struct ProfScope {
     }
 };
 
+// Bits of the tile field the partition sorts on: the reference's getHigherMsb(tiles) (rasterizer_impl.cu:301), capped
+// at the 16 bits the field has -- for exactly 65 536 tiles getHigherMsb says 17, which would shift a 64-bit key by 64.
 uint32_t higher_msb(uint32_t n) {  // rasterizer_impl.cu:35-50
     uint32_t msb = sizeof(n) * 4, step = msb;
     while (step > 1) {
@@ -115,6 +117,10 @@ uint32_t higher_msb(uint32_t n) {  // rasterizer_impl.cu:35-50
     }
     if (n >> msb) msb++;
     return msb;
+}
+int tile_sort_bits(int tiles) {
+    const int b = (int)higher_msb((uint32_t)tiles);
+    return b < 16 ? b : 16;
 }
 
 }  // namespace
@@ -165,7 +171,7 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     const BinLayout b = bin_layout((size_t)R);
     const ImgLayout im = img_layout((size_t)width * height, (size_t)tiles);
     // which ping-pong half holds the results is fixed by the (even / data-independent) pass counts
-    const int tile_bits = (int)higher_msb((uint32_t)tiles);
+    const int tile_bits = tile_sort_bits(tiles);
     const int passes = (tile_bits + 7) / 8;
     out->rec = g.rec;
     out->clamped = g.clamped;
@@ -327,7 +333,7 @@ static int rasterizer_forward_impl(
               launch_emit(V_emit, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, nblocks_v,
                           stream); }
             CHECK_LAUNCH("emit");
-            const int tile_bits = (int)higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:301
+            const int tile_bits = tile_sort_bits(tiles);  // rasterizer_impl.cu:301
             int c2;
             { ProfScope ps(PF_TILE_SORT, stream);
               c2 = radix_sort_u64_keys(ent_a, ent_b, R_binned, ENTRY_TILE_SHIFT, ENTRY_TILE_SHIFT + tile_bits,
@@ -448,7 +454,7 @@ static int rasterizer_backward_impl(
     if (R > 0) HIP_TRY(hipMemsetAsync(rec_flag, 0, align_up((size_t)R) + 256, stream));
     if (R > 0) {
         char* bin = align_ptr(binning_buffer);
-        const int tile_bits = (int)higher_msb((uint32_t)tiles);
+        const int tile_bits = tile_sort_bits(tiles);
         const int passes = (tile_bits + 7) / 8;
         BlendBwdArgs bb{};
         bb.W = width; bb.H = height; bb.tiles_x = tiles_x; bb.tiles_y = tiles_y;

@@ -559,3 +559,28 @@ def test_hair_thin_splat_found_by_the_fuzz_sweep(hip_lib, oracle_mod):
     h = run_hip(inp, g)
     check_forward(h, o)
     check_grads(h, o)
+
+
+def test_largest_tile_grid(hip_lib, oracle_mod):
+    """4096 x 4096 = 65 536 tiles, the documented limit (16-bit tile ids): forward + backward against the oracle, and one
+    pixel more in either direction is refused with an error instead of overflowing."""
+    import torch
+    from g4splat_amd.diff_surfel_rasterization import _C
+    inp = scene_inputs(P=3000, W=4096, H=4096, seed=91, D=1, scale_mul=1.5)
+    g = cotangents(4096, 4096, seed=6)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    # ~10^9 (pixel, splat) evaluations: the statistical bar of test_metric_size_vs_oracle (rare threshold flips)
+    assert h["R"] == o["R"]
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    N = 4096 * 4096
+    bad = (np.abs(h["color"] - o["color"]).max(axis=0) > OUT_ATOL) | (np.abs(h["others"] - o["others"]).max(axis=0) > OUT_ATOL)
+    assert bad.sum() <= 2e-5 * N, int(bad.sum())
+    assert np.median(np.abs(h["color"] - o["color"])) <= 1e-6
+    for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
+        a, b = h["grads"][name].astype(np.float64), o["grads"][name].astype(np.float64)
+        assert np.linalg.norm(a - b) <= GRAD_RTOL * np.linalg.norm(b), name
+    big = dict(inp)
+    big["W"] = 4097
+    with pytest.raises(RuntimeError, match="tiles"):
+        run_hip(big)
