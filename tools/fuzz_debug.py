@@ -25,6 +25,10 @@ for seed in [int(x) for x in sys.argv[1:]]:
         inp["scales"] = (inp["scales"] * np.array([[8.0, 0.1]], np.float32)).astype(np.float32)
     elif kind == 2:
         inp["scales"] = (inp["scales"] * np.array([[0.01, 40.0]], np.float32)).astype(np.float32)
+    scene_scale = float(os.environ.get("FUZZ_SCENE_SCALE", "1"))
+    if scene_scale != 1.0:
+        inp["means3D"] = (inp["means3D"] * scene_scale).astype(np.float32)
+        inp["scales"] = (inp["scales"] * scene_scale).astype(np.float32)
     g = cotangents(H, W, seed=seed)
     o = run_oracle(oracle_mod, inp, g)
     print(f"seed {seed}: P={P} {W}x{H} D={D} kind={kind} R={o['R']} scale_modifier={inp['scale_modifier']}")
@@ -40,6 +44,9 @@ for seed in [int(x) for x in sys.argv[1:]]:
         st = hip_state(h, inp)
         last_h = st["n_contrib"][0].reshape(H, W)[y, x]
         last_o = o["oracle"].state("n_contrib").reshape(2, H, W)[0][y, x]
+        per_map = [float(np.abs(h["others"][c] - o["others"][c]).max()) for c in range(7)]
+        print("   others per map (depth, alpha, n0, n1, n2, median, distortion):", ["%.2e" % v for v in per_map],
+              "max |depth|", float(np.abs(o["others"][0]).max()), "max |median|", float(np.abs(o["others"][5]).max()))
         print(f"   {env or 'default'}: {nbad} pixels beyond 1e-4, worst {d.max():.3e} at ({x},{y}) others worst {do.max():.3e}; "
               f"alpha hip {h['others'][1][y, x]:.6f} oracle {o['others'][1][y, x]:.6f}; last contributor hip(list pos) {last_h} oracle {last_o}")
     for k in ("G4S_BOX_ONLY", "G4S_NO_FASTPATH"):

@@ -33,6 +33,10 @@ for seed in range(first, first + count):
         inp["scales"] = (inp["scales"] * np.array([[8.0, 0.1]], np.float32)).astype(np.float32)
     elif kind == 2:
         inp["scales"] = (inp["scales"] * np.array([[0.01, 40.0]], np.float32)).astype(np.float32)
+    scene_scale = float(os.environ.get("FUZZ_SCENE_SCALE", "1"))  # uniform scaling of the scene about the camera
+    if scene_scale != 1.0:
+        inp["means3D"] = (inp["means3D"] * scene_scale).astype(np.float32)
+        inp["scales"] = (inp["scales"] * scene_scale).astype(np.float32)
     g = cotangents(H, W, seed=seed)
     o = run_oracle(oracle_mod, inp, g)
     for mode in ("policy", "one-wave"):
