@@ -291,7 +291,8 @@ def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys):
     from g4splat_amd import synthetic
     P, W, H = 1_500_000, 1600, 1200
     scene = synthetic.scene_room(P, seed=0)
-    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[5]
+    import os
+    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[int(os.environ.get("G4S_TEST_VIEW", "5"))]  # (other views: a manual sweep)
     inp = dict(bg=np.array([0.3, 0.1, 0.2], np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
                scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
                view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
