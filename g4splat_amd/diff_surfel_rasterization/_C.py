@@ -63,6 +63,26 @@ class _Scratch:
         self.cb = _lib.RESIZE_FN(_resize)
 
 
+def _check_shapes(P, background, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh, campos):
+    """The native side takes raw pointers (like the reference's, which would read garbage): refuse tensors whose
+    element counts cannot be what the kernels index -- e.g. 3-D Gaussian splatting's [P,3] scales."""
+    def want(t, n, what):
+        if t is not None and t.numel() and t.numel() != n:
+            raise RuntimeError(f"{what} has {t.numel()} elements, expected {n}")
+    want(background, 3, "background [3]")
+    want(colors, 3 * P, "colors_precomp [P,3]")
+    want(opacity, P, "opacity [P,1]")
+    want(scales, 2 * P, "scales [P,2] (surfels have two scales)")
+    want(rotations, 4 * P, "rotations [P,4]")
+    want(transMat_precomp, 9 * P, "transMat_precomp [P,9]")
+    want(viewmatrix, 16, "viewmatrix [4,4]")
+    want(projmatrix, 16, "projmatrix [4,4]")
+    want(campos, 3, "campos [3]")
+    if sh is not None and not isinstance(sh, (tuple, list)) and sh.numel():
+        if sh.ndim != 3 or sh.size(0) != P or sh.size(2) != 3:
+            raise RuntimeError(f"sh must have dimensions (num_points, M, 3), got {tuple(sh.shape)}")
+
+
 def _check_split_sh(sh_dc, sh_rest, means3D, colors):
     P = int(means3D.size(0))
     if sh_dc.ndim != 3 or tuple(sh_dc.shape) != (P, 1, 3) or sh_rest.ndim != 3 or sh_rest.size(0) != P or sh_rest.size(2) != 3:
@@ -91,6 +111,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _check_split_sh(sh_dc, sh_rest, means3D, colors)
     lib = _lib.load()
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    _check_shapes(P, background, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh, campos)
     dev = means3D.device
     with torch.cuda.device(dev):
         fopt = dict(dtype=torch.float32, device=dev)
@@ -148,6 +169,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         _check_split_sh(sh_dc, sh_rest, means3D, colors)
     lib = _lib.load()
     P = int(means3D.size(0))
+    _check_shapes(P, background, colors, None, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh, campos)
+    if radii.numel() != P:
+        raise RuntimeError(f"radii has {radii.numel()} elements, expected {P}")
+    if dL_dout_color.ndim != 3 or dL_dout_color.size(0) != 3 or tuple(dL_dout_others.shape) != (7,) + tuple(dL_dout_color.shape[1:]):
+        raise RuntimeError("dL_dout_color must be [3,H,W] and dL_dout_others [7,H,W]")
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = (1 + int(sh_rest.size(1))) if split else (int(sh.size(1)) if sh.size(0) != 0 else 0)
     dev = means3D.device

@@ -262,3 +262,28 @@ def test_more_than_four_million_emitting_gaussians(hip_lib):
     assert torch.equal(ra[perm], rb)
     assert torch.equal(ca, cb) and torch.equal(oa, ob)
     assert float(oa[1].max()) > 0.5  # the frame is really covered
+
+
+def test_wrong_element_counts_are_refused(hip_lib):
+    """Raw pointers go to the native side: tensors with the wrong number of elements (3-D Gaussian splatting's [P,3]
+    scales, a [3,3] view matrix, ...) are refused with a message instead of being read out of bounds."""
+    from g4splat_amd.diff_surfel_rasterization import _C
+    dev = torch.device("cuda:0")
+    P = 50
+    z = lambda *s: torch.zeros(s, device=dev)
+    e = torch.empty(0, device=dev)
+    ok = dict(bg=z(3), m=z(P, 3), col=e, opa=z(P, 1), sc=z(P, 2), rot=z(P, 4), tm=e, view=torch.eye(4, device=dev),
+              proj=torch.eye(4, device=dev), sh=z(P, 16, 3), cam=z(3))
+
+    def call(**over):
+        a = dict(ok, **over)
+        return _C.rasterize_gaussians(a["bg"], a["m"], a["col"], a["opa"], a["sc"], a["rot"], 1.0, a["tm"], a["view"], a["proj"],
+                                      1.0, 1.0, 32, 32, a["sh"], 3, a["cam"], False, False)
+
+    call()  # the well-formed call goes through
+    for over, msg in ((dict(sc=z(P, 3)), "scales"), (dict(rot=z(P, 3)), "rotations"), (dict(opa=z(P - 1, 1)), "opacity"),
+                      (dict(view=torch.eye(3, device=dev)), "viewmatrix"), (dict(bg=z(4)), "background"),
+                      (dict(sh=z(P, 16)), "sh must have"), (dict(sh=z(P + 1, 16, 3)), "sh must have"),
+                      (dict(cam=z(2)), "campos")):
+        with pytest.raises(RuntimeError, match=msg):
+            call(**over)
