@@ -37,6 +37,16 @@ for seed in range(first, first + count):
     if scene_scale != 1.0:
         inp["means3D"] = (inp["means3D"] * scene_scale).astype(np.float32)
         inp["scales"] = (inp["scales"] * scene_scale).astype(np.float32)
+    if os.environ.get("FUZZ_PRECOMP"):  # colours and / or the T matrices handed in precomputed (no SH, no scale + rotation)
+        o0 = run_oracle(oracle_mod, inp)
+        which = seed % 3
+        if which in (0, 2):
+            inp["colors"] = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+            inp["sh"] = np.zeros((0,), np.float32)
+        if which in (1, 2):
+            inp["transMat"] = o0["oracle"].state("transMat").copy()
+            inp["scales"] = np.zeros((0,), np.float32)
+            inp["rotations"] = np.zeros((0,), np.float32)
     g = cotangents(H, W, seed=seed)
     o = run_oracle(oracle_mod, inp, g)
     for mode in ("policy", "one-wave"):
@@ -53,7 +63,10 @@ for seed in range(first, first + count):
             assert np.abs(h["others"] - o["others"]).max() <= OUT_ATOL, "others"
             if o["R"] > 0 and mode == "policy":
                 check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
-            for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
+            for name in ("means3D", "scales", "rotations", "opacity", "sh", "colors", "transMat", "means2D"):
+                if o["grads"][name].size == 0 or h["grads"][name].size == 0:
+                    assert o["grads"][name].size == h["grads"][name].size or name in ("sh", "scales", "rotations", "colors"), "grad size " + name
+                    continue
                 assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, "grad " + name
         except AssertionError as ex:
             # a mismatch that survives G4S_BOX_ONLY is a threshold flip of the per-pixel arithmetic (one contributor at
