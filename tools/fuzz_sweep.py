@@ -48,6 +48,16 @@ for seed in range(first, first + count):
             inp["scales"] = np.zeros((0,), np.float32)
             inp["rotations"] = np.zeros((0,), np.float32)
     g = cotangents(H, W, seed=seed)
+    cot = os.environ.get("FUZZ_COT", "")  # sparse cotangents: only some of the ten output maps carry a gradient
+    if cot:
+        gc, go = g[0].copy(), g[1].copy()
+        pick = seed % 5
+        if pick == 0: go[:] = 0                      # colour loss only
+        elif pick == 1: gc[:] = 0; go[1:] = 0        # depth only
+        elif pick == 2: gc[:] = 0; go[:5] = 0; go[6] = 0   # median depth only
+        elif pick == 3: gc[:] = 0; go[:6] = 0        # distortion only
+        else: gc[:] = 0; go[0:2] = 0; go[5:] = 0     # normals only
+        g = (gc, go)
     o = run_oracle(oracle_mod, inp, g)
     for mode in ("policy", "one-wave"):
         if mode == "one-wave":
@@ -66,6 +76,20 @@ for seed in range(first, first + count):
             for name in ("means3D", "scales", "rotations", "opacity", "sh", "colors", "transMat", "means2D"):
                 if o["grads"][name].size == 0 or h["grads"][name].size == 0:
                     assert o["grads"][name].size == h["grads"][name].size or name in ("sh", "scales", "rotations", "colors"), "grad size " + name
+                    continue
+                if np.abs(o["grads"][name]).max() == 0:
+                    assert np.abs(h["grads"][name]).max() == 0, "grad (expected zero) " + name
+                    continue
+                if cot:
+                    # With a single map's cotangent some gradients are mathematically zero (the median depth of a
+                    # ray-plane intersection does not depend on the in-plane scales, ...): both sides then return the
+                    # rounding noise of cancelling terms.  Judge against the frame's overall gradient scale as well.
+                    S = max(float(np.abs(o["grads"][n]).max()) for n in ("means3D", "transMat", "opacity") if o["grads"][n].size)
+                    d = float(np.abs(h["grads"][name].astype(np.float64) - o["grads"][name]).max())
+                    # (distortion of one or two splats, median depth w.r.t. scales: exactly zero in exact arithmetic --
+                    # what is left is the random walk of ~H W roundings of O(|cotangent|) terms)
+                    floor = 1e-7 * np.sqrt(H * W) * max(float(np.abs(g[0]).max()), float(np.abs(g[1]).max()))
+                    assert d <= GRAD_RTOL * float(np.abs(o["grads"][name]).max()) + 1e-4 * S + floor, "grad " + name
                     continue
                 assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, "grad " + name
         except AssertionError as ex:
