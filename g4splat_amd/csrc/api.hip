@@ -220,7 +220,7 @@ static int rasterizer_forward_impl(
     uint32_t* ranges = (uint32_t*)(img + IL.ranges);
     float* final_T = (float*)(img + IL.final_T);
     uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
-    HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, stream));  // rasterizer_impl.cu:311
+    if (P <= 0) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, stream));  // rasterizer_impl.cu:311 (P > 0: cleared by the totals scan)
 
     int R = 0;
     const float* rec_ptr = nullptr;
@@ -275,7 +275,7 @@ static int rasterizer_forward_impl(
         uint32_t* vis_block_offs = (uint32_t*)(geom + GL.vis_block_offs);
         { ProfScope ps(PF_COUNT_SCAN, stream);
           launch_scan_totals(pa.idx_block_sums, idx_block_offs, pa.ref_block_sums, pa.vis_block_sums, vis_block_offs,
-                             d_total, GL.nblocks, stream); }
+                             d_total, GL.nblocks, ranges, tiles * 2, stream); }
         CHECK_LAUNCH("scan totals");
         uint32_t* h_total = pinned_word();
         if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
@@ -288,21 +288,22 @@ static int rasterizer_forward_impl(
         // not depend on them, and the pack / depth sort / count of the emitting Gaussians read V (d_total[2]) on the
         // device, their launches sized for P.  The GPU therefore has ~0.1 ms of work queued while the host reads the
         // totals back, sizes the binning chunk and issues the rest: the read-back no longer drains the queue.
-        launch_grad_slots(P, tiles_touched, idx_block_offs, rec, GL.nblocks, stream);
-        CHECK_LAUNCH("grad slots");
         const uint32_t* d_V = d_total + 2;
         const uint32_t* gidx_sorted;
+        uint32_t* rank_local;
         {   // depth order of the emitting Gaussians (stable => ties by ascending index): pack, then sort
             ProfScope ps(PF_DEPTH_SORT, stream);
-            launch_compact_keys(P, tiles_touched, keys_a, vis_block_offs, keys_b, vals_b, GL.nblocks, stream);
+            launch_slots_and_compact(P, tiles_touched, idx_block_offs, rec, keys_a, vis_block_offs, keys_b, vals_b,
+                                     GL.nblocks, stream);
             const int cur = radix_sort_u32_pairs(keys_b, keys_a, vals_b, vals_a, P, (uint32_t*)(geom + GL.hist),
                                                  (uint32_t*)(geom + GL.bin_total), stream, d_V);
             gidx_sorted = cur ? vals_a : vals_b;
+            rank_local = cur ? keys_b : keys_a;  // the key array the sort no longer needs
         }
         CHECK_LAUNCH("depth sort");
         {
             ProfScope ps(PF_COUNT_SCAN, stream);
-            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, block_sums, d_total + 4, GL.nblocks,
+            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, rank_local, d_total + 4, GL.nblocks,
                               stream, d_V);
         }
         CHECK_LAUNCH("count scan");
@@ -328,10 +329,9 @@ static int rasterizer_forward_impl(
         entries_ptr = ent_a;
         qhit_ptr = (uint8_t*)(bin + BL.qhit);
         if (R_binned > 0) {
-            HIP_TRY(hipMemsetAsync(qhit_ptr, 0, align_up((size_t)R_binned, 256), stream));  // whole 256-B granules: a ragged byte count takes a slow fill path
-            { ProfScope ps(PF_EMIT, stream);
-              launch_emit(V_emit, tiles_x, tiles_y, gidx_sorted, tiles_touched, block_offs, radii, rec, ent_a, nblocks_v,
-                          stream); }
+            { ProfScope ps(PF_EMIT, stream);  // (also clears the contribution masks qhit[0, R_binned))
+              launch_emit(V_emit, (uint32_t)R_binned, tiles_x, tiles_y, gidx_sorted, block_offs, nblocks_v, rank_local,
+                          radii, rec, ent_a, qhit_ptr, stream); }
             CHECK_LAUNCH("emit");
             const int tile_bits = tile_sort_bits(tiles);  // rasterizer_impl.cu:301
             int c2;

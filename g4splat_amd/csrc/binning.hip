@@ -38,9 +38,18 @@ __global__ void __launch_bounds__(64) radix_hist_kernel(const K* __restrict__ ke
     __syncthreads();
     const int begin = chunk * chunk_len;
     const int end = imin_(n, begin + chunk_len);
-    for (int i = begin + lane; i < end; i += 64) {
-        const uint32_t d = (uint32_t)(keys[i] >> shift) & 0xFFu;
-        atomicAdd(&h[d], 1u);
+    // eight independent loads in flight per lane: a chunk is walked by ONE wave, so without this every step
+    // of 64 keys would expose a full memory round trip
+    for (int base = begin; base < end; base += 64 * 8) {
+        K k[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = base + 64 * u + lane;
+            k[u] = keys[i < end ? i : begin];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (base + 64 * u + lane < end) atomicAdd(&h[(uint32_t)(k[u] >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
     for (int i = lane; i < 256; i += 64) hist[(size_t)i * nchunks + chunk] = h[i];
@@ -107,34 +116,46 @@ __global__ void __launch_bounds__(64) radix_scatter_kernel(const K* __restrict__
     const int begin = chunk * chunk_len;
     const int end = imin_(n, begin + chunk_len);
     const uint64_t below = lanes_below_mask();
-    for (int base = begin; base < end; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < end;
-        K key = 0;
-        uint32_t val = 0;
-        if (valid) {
-            key = keys_in[i];
-            if (HAS_VAL) val = vals_in[i];
-        }
-        const uint32_t d = (uint32_t)(key >> shift) & 0xFFu;
-        // match-any over the 8 digit bits
-        uint64_t m = __ballot(valid);
+    // Eight steps of 64 keys are fetched together (independent loads in flight), then ranked one after the other:
+    // a chunk is walked by one wave, so a load per step would expose a memory round trip per step.
+    constexpr int G = 8;
+    for (int base0 = begin; base0 < end; base0 += 64 * G) {
+        K kk[G];
+        uint32_t vv[G];
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+        for (int u = 0; u < G; u++) {
+            const int i = base0 + 64 * u + lane;
+            const int ic = i < end ? i : begin;
+            kk[u] = keys_in[ic];
+            vv[u] = HAS_VAL ? vals_in[ic] : 0u;
         }
-        const uint32_t rank = (uint32_t)__popcll(m & below);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        uint32_t dst = 0;
-        if (valid) dst = offs[d] + rank;
-        __syncthreads();  // single-wave block: orders the LDS read above against the update below
-        if (valid && rank == cnt - 1) offs[d] += cnt;
-        __syncthreads();
-        if (valid) {
-            keys_out[dst] = key;
-            if (HAS_VAL) vals_out[dst] = val;
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int base = base0 + 64 * u;
+            if (base >= end) break;  // uniform
+            const bool valid = base + lane < end;
+            const K key = kk[u];
+            const uint32_t val = vv[u];
+            const uint32_t d = (uint32_t)(key >> shift) & 0xFFu;
+            // match-any over the 8 digit bits
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(m & below);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            uint32_t dst = 0;
+            if (valid) dst = offs[d] + rank;
+            __syncthreads();  // single-wave block: orders the LDS read above against the update below
+            if (valid && rank == cnt - 1) offs[d] += cnt;
+            __syncthreads();
+            if (valid) {
+                keys_out[dst] = key;
+                if (HAS_VAL) vals_out[dst] = val;
+            }
         }
     }
 }
@@ -182,10 +203,12 @@ int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_
 // ---------------------------------------------------------------------------------------
 // instance counting (in depth order), emission, tile ranges
 
-// tiles_touched gathered in depth order, 256 per block -> block sums.
+// tiles_touched gathered in depth order, 256 per block -> block sums; every rank also keeps its exclusive offset
+// inside its block (rank_local), so that block_offs[r >> 8] + rank_local[r] is the first output slot of depth rank r.
 __global__ void __launch_bounds__(256) count_block_sums_kernel(int P, const uint32_t* __restrict__ gidx,
                                                                const uint32_t* __restrict__ tiles_touched,
                                                                uint32_t* __restrict__ block_sums,
+                                                               uint32_t* __restrict__ rank_local,
                                                                const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t sm4[4];
     if (d_n != nullptr) {  // device-side count: blocks past the end leave
@@ -196,169 +219,204 @@ __global__ void __launch_bounds__(256) count_block_sums_kernel(int P, const uint
     uint32_t c = 0;
     if (r < P) c = tiles_touched[gidx[r]];
     uint32_t total;
-    block256_excl_scan_u32(c, sm4, &total);
+    const uint32_t local = block256_excl_scan_u32(c, sm4, &total);
+    if (r < P) rank_local[r] = local;
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// Single block: exclusive scan of the block sums, grand total to *total.
-__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, const uint32_t* __restrict__ block_sums,
-                                                               uint32_t* __restrict__ block_offs,
-                                                               const uint32_t* __restrict__ ref_block_sums,
-                                                               uint32_t* __restrict__ total,
+// Single block: exclusive scan of up to two arrays of block sums (b may be NULL), the sum of a third (ref, may be
+// NULL), and an optional clear of `zero_words` 32-bit words (the tile ranges, rasterizer_impl.cu:311 -- folded in
+// here to save a launch).  Totals: total_a[0] = sum(a), total_a[1] = sum(ref), total_b[0] = sum(b).
+__global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, const uint32_t* __restrict__ a_sums,
+                                                               uint32_t* __restrict__ a_offs,
+                                                               const uint32_t* __restrict__ b_sums,
+                                                               uint32_t* __restrict__ b_offs,
+                                                               const uint32_t* __restrict__ ref_sums,
+                                                               uint32_t* __restrict__ total_a, uint32_t* __restrict__ total_b,
+                                                               uint32_t* __restrict__ zero_ptr, int zero_words,
                                                                const uint32_t* __restrict__ d_n) {
-    __shared__ uint32_t wsum[16], rsum[16];
+    __shared__ uint32_t wa[16], wb[16], wr[16];
     const int t = (int)threadIdx.x;
+    for (int i = t; i < zero_words; i += 1024) zero_ptr[i] = 0u;
     if (d_n != nullptr) nblocks = (int)((*d_n + 255u) / 256u);  // blocks of a device-side element count
     const int seg = (nblocks + 1023) / 1024;
     const int b = imin_(nblocks, t * seg), e = imin_(nblocks, b + seg);
-    uint32_t sum = 0, ref = 0;
+    uint32_t sa = 0, sb = 0, sr = 0;
     for (int i = b; i < e; i++) {
-        sum += block_sums[i];
-        ref += ref_block_sums[i];
+        sa += a_sums[i];
+        if (b_sums) sb += b_sums[i];
+        if (ref_sums) sr += ref_sums[i];
     }
-    const uint32_t inc = wave_incl_scan_u32(sum);
-    const uint32_t rinc = wave_incl_scan_u32(ref);
+    const uint32_t ia = wave_incl_scan_u32(sa), ib = wave_incl_scan_u32(sb), ir = wave_incl_scan_u32(sr);
     if ((t & 63) == 63) {
-        wsum[t >> 6] = inc;
-        rsum[t >> 6] = rinc;
+        wa[t >> 6] = ia;
+        wb[t >> 6] = ib;
+        wr[t >> 6] = ir;
     }
     __syncthreads();
-    uint32_t base = 0, all = 0, rall = 0;
+    uint32_t base_a = 0, base_b = 0, all_a = 0, all_b = 0, all_r = 0;
     for (int w = 0; w < 16; w++) {
-        if (w < (t >> 6)) base += wsum[w];
-        all += wsum[w];
-        rall += rsum[w];
+        if (w < (t >> 6)) { base_a += wa[w]; base_b += wb[w]; }
+        all_a += wa[w];
+        all_b += wb[w];
+        all_r += wr[w];
     }
-    uint32_t run = base + inc - sum;
+    uint32_t run_a = base_a + ia - sa, run_b = base_b + ib - sb;
     for (int i = b; i < e; i++) {
-        block_offs[i] = run;
-        run += block_sums[i];
+        a_offs[i] = run_a;
+        run_a += a_sums[i];
+        if (b_sums) { b_offs[i] = run_b; run_b += b_sums[i]; }
     }
     if (t == 0) {
-        total[0] = all;
-        total[1] = rall;
+        total_a[0] = all_a;
+        total_a[1] = all_r;
+        if (b_sums) total_b[0] = all_b;
     }
 }
 
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
-                       uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
-                       hipStream_t s, const uint32_t* d_n) {
+                       uint32_t* block_offs, uint32_t* rank_local, uint32_t* total, int nblocks, hipStream_t s,
+                       const uint32_t* d_n) {
     // d_n != nullptr: P / nblocks only bound the grid, the kernels read the count from the device
     hipLaunchKernelGGL(count_block_sums_kernel, dim3(nblocks), dim3(256), 0, s, P, gidx_sorted, tiles_touched,
-                       block_sums, d_n);
+                       block_sums, rank_local, d_n);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs,
-                       ref_block_sums, total, d_n);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, total, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, 0, d_n);
 }
 
-// Load-balanced expansion: a block owns 256 consecutive depth ranks; its output range is
-// contiguous, every thread produces output slots (not Gaussians), so stores are coalesced
-// and the work per thread is even no matter how skewed the per-Gaussian tile counts are.
-__global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles_y,
+// Load-balanced expansion, partitioned by OUTPUT: a block owns EMIT_SLOTS consecutive instance slots, whatever
+// Gaussians they belong to -- the nearest splats cover hundreds of tiles each, the far ones one or two, and a block
+// per 256 depth ranks (the first design) left the few blocks of the nearest ranks running ten times longer than the
+// rest.  Every depth rank emits at least one instance, so at most EMIT_SLOTS + 1 ranks reach into a block's window:
+// the first one is found with three block-wide counting steps over the monotone offset arrays (no serial binary
+// search over global memory), their offsets, indices and tile rects are staged in LDS, and every thread then
+// produces output slots: a binary search in the LDS offsets, one coalesced 8-byte store per slot.
+// The block also clears its slots of the forward's contribution masks (qhit), which saves a memset launch.
+constexpr int EMIT_SLOTS = 1024;
+__global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tiles_x, int tiles_y,
                                                    const uint32_t* __restrict__ gidx,
-                                                   const uint32_t* __restrict__ tiles_touched,
-                                                   const uint32_t* __restrict__ block_offs,
-                                                   const int* __restrict__ radii, float* __restrict__ rec,
-                                                   uint64_t* __restrict__ entries) {
-    __shared__ uint32_t sm4[4];
-    __shared__ uint32_t s_off[256];   // exclusive local offsets
-    __shared__ uint32_t s_idx[256];
-    __shared__ uint32_t s_rect[256];  // x0 | y0<<12 | width<<24 is too narrow for big grids: use two words
-    __shared__ uint32_t s_rect2[256];
+                                                   const uint32_t* __restrict__ block_offs, int nblocks_v,
+                                                   const uint32_t* __restrict__ rank_local,
+                                                   const int* __restrict__ radii, const float* __restrict__ rec,
+                                                   uint64_t* __restrict__ entries, uint8_t* __restrict__ qhit) {
+    __shared__ uint32_t s_off[EMIT_SLOTS + 4];  // first slot of the staged ranks (ascending), then a sentinel
+    __shared__ uint32_t s_idx[EMIT_SLOTS + 4];
+    __shared__ uint32_t s_rect[EMIT_SLOTS + 4];   // x0 | y0 << 16
+    __shared__ uint32_t s_rect2[EMIT_SLOTS + 4];  // rect width in tiles
+    __shared__ uint32_t s_nr;
     const int t = (int)threadIdx.x;
-    const int r = (int)(blockIdx.x * 256 + t);
-    uint32_t cnt = 0, idx = 0;
-    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    if (r < P) {
-        idx = gidx[r];
-        cnt = tiles_touched[idx];
-        if (cnt > 0) {
-            const float4* rq = reinterpret_cast<const float4*>(rec) + (size_t)idx * REC_QUADS;
-            const float4 q0 = rq[0], q5 = rq[5];
-            int rx0, ry0, rx1, ry1;
-            get_rect(q0.x, q0.y, radii[idx], tiles_x, tiles_y, rx0, ry0, rx1, ry1);
-            tight_tile_rect(q5, rx0, ry0, rx1, ry1, x0, y0, x1, y1);  // same arithmetic as the preprocess
-        }
+    const uint32_t w0 = blockIdx.x * (uint32_t)EMIT_SLOTS;
+    const uint32_t w1 = min(w0 + (uint32_t)EMIT_SLOTS, R_b);
+    // contribution masks of this window (bytes [w0, w1)); w0 is a multiple of 1024, the array base 256-B aligned
+    {
+        const uint32_t o = w0 + 4u * (uint32_t)t;
+        if (o + 4u <= w1) *reinterpret_cast<uint32_t*>(qhit + o) = 0u;
+        else for (uint32_t i = o; i < w1; i++) qhit[i] = 0;
     }
-    uint32_t block_total;
-    const uint32_t local = block256_excl_scan_u32(cnt, sm4, &block_total);
-    const uint32_t base = block_offs[blockIdx.x];
-    s_off[t] = local;
-    s_idx[t] = idx;
-    s_rect[t] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-    s_rect2[t] = (uint32_t)(x1 - x0);
+    if (t == 0) s_nr = 0;
+    // the 256-rank group that holds slot w0: last g with block_offs[g] <= w0 (block_offs[0] == 0)
+    int lo = 0, n = nblocks_v;
+    while (n > 1) {  // uniform; two rounds up to 65 536 groups
+        const int S = (n + 255) / 256;
+        const int j = lo + t * S;
+        const int c = __syncthreads_count(t * S < n && block_offs[j] <= w0);
+        lo += (c - 1) * S;
+        n = imin_(S, n - (c - 1) * S);
+    }
+    const int g = lo;
+    const uint32_t goff = block_offs[g];
+    int r_first;
+    {
+        const int r = 256 * g + t;
+        const int c = __syncthreads_count(r < V && goff + rank_local[r] <= w0);
+        r_first = 256 * g + c - 1;
+    }
+    // stage the ranks whose first slot lies below w1
+    for (int i = t; i <= EMIT_SLOTS; i += 256) {
+        const int r = r_first + i;
+        if (r >= V) break;
+        const uint32_t off = block_offs[r >> 8] + rank_local[r];
+        if (off >= w1) break;  // offsets ascend with the rank: nothing further on for this thread either
+        const uint32_t idx = gidx[r];
+        const float4* rq = reinterpret_cast<const float4*>(rec) + (size_t)idx * REC_QUADS;
+        const float4 q0 = rq[0], q5 = rq[5];
+        int rx0, ry0, rx1, ry1, x0, y0, x1, y1;
+        get_rect(q0.x, q0.y, radii[idx], tiles_x, tiles_y, rx0, ry0, rx1, ry1);
+        tight_tile_rect(q5, rx0, ry0, rx1, ry1, x0, y0, x1, y1);  // same arithmetic as the preprocess
+        s_off[i] = off;
+        s_idx[i] = idx;
+        s_rect[i] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        s_rect2[i] = (uint32_t)(x1 - x0);
+        atomicMax(&s_nr, (uint32_t)i + 1u);
+    }
     __syncthreads();
-    for (uint32_t o = (uint32_t)t; o < block_total; o += 256) {
-        // largest j with s_off[j] <= o  (zero-count ranks share an offset with their successor,
-        // the search lands on the last of them, i.e. the one that owns slot o)
-        int lo = 0, hi = 255;
+    const int nr = (int)s_nr;  // >= 1: rank r_first always qualifies
+    for (uint32_t o = w0 + (uint32_t)t; o < w1; o += 256) {
+        // largest j < nr with s_off[j] <= o
+        int a = 0, b = nr - 1;
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_off[mid] <= o) lo = mid; else hi = mid - 1;
+        for (int it = 0; it < 11; it++) {  // 2^11 > EMIT_SLOTS + 1
+            const int mid = (a + b + 1) >> 1;
+            if (s_off[mid] <= o) a = mid; else b = mid - 1;
         }
-        const uint32_t k = o - s_off[lo];
-        const uint32_t w = s_rect2[lo];
-        const uint32_t rx0 = s_rect[lo] & 0xFFFFu, ry0 = s_rect[lo] >> 16;
+        const uint32_t k = o - s_off[a];
+        const uint32_t w = s_rect2[a];
+        const uint32_t rx0 = s_rect[a] & 0xFFFFu, ry0 = s_rect[a] >> 16;
         const uint32_t ty = k / w, tx = k - ty * w;
         const uint64_t tile = (uint64_t)((ry0 + ty) * (uint32_t)tiles_x + rx0 + tx);
-        entries[(size_t)base + o] =
-            (tile << ENTRY_TILE_SHIFT) | ((uint64_t)k << ENTRY_K_SHIFT) | (uint64_t)s_idx[lo];
+        entries[o] = (tile << ENTRY_TILE_SHIFT) | ((uint64_t)k << ENTRY_K_SHIFT) | (uint64_t)s_idx[a];
     }
 }
 
-__global__ void __launch_bounds__(256) grad_slots_kernel(int P, const uint32_t* __restrict__ tiles_touched,
-                                                         const uint32_t* __restrict__ idx_block_offs,
-                                                         float* __restrict__ rec) {
-    __shared__ uint32_t sm4[4];
+// Index-order pass behind the totals scan, two jobs in one launch:
+//  * gradient-record slots: rec[idx].inst_off = exclusive scan of tiles_touched over idx (so that the
+//    per-Gaussian fold of the backward streams the record buffer sequentially);
+//  * the (depth key, index) pairs of the Gaussians that emit instances (typically a quarter of the scene) are
+//    packed in index order -- only they take part in the depth sort and in everything after it, and the stable
+//    sort still resolves equal depths by ascending index.
+__global__ void __launch_bounds__(256) slots_and_compact_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                                const uint32_t* __restrict__ idx_block_offs,
+                                                                float* __restrict__ rec,
+                                                                const uint32_t* __restrict__ depth_keys,
+                                                                const uint32_t* __restrict__ vis_block_offs,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ idx_out) {
+    __shared__ uint32_t sm4[4], sm4b[4];
     const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
     const uint32_t c = idx < P ? tiles_touched[idx] : 0u;
     uint32_t total;
-    const uint32_t local = block256_excl_scan_u32(c, sm4, &total);
-    if (c > 0) rec[(size_t)idx * REC_FLOATS + 2] = __uint_as_float(idx_block_offs[blockIdx.x] + local);
-}
-void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec, int nblocks,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(grad_slots_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_touched, idx_block_offs, rec);
-}
-
-void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
-                        const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
-                       ref_block_sums, total, (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, vis_block_sums, vis_block_offs,
-                       vis_block_sums, total + 2, (const uint32_t*)nullptr);
-}
-
-// Only Gaussians that emit instances take part in the depth sort and in everything after it (typically a
-// quarter of the scene): their (depth key, index) pairs are packed in index order, so the stable sort still
-// resolves equal depths by ascending index.
-__global__ void __launch_bounds__(256) compact_keys_kernel(int P, const uint32_t* __restrict__ tiles_touched,
-                                                           const uint32_t* __restrict__ depth_keys,
-                                                           const uint32_t* __restrict__ vis_block_offs,
-                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
-    __shared__ uint32_t sm4[4];
-    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-    const bool emits = idx < P && tiles_touched[idx] > 0;
-    uint32_t total;
-    const uint32_t local = block256_excl_scan_u32(emits ? 1u : 0u, sm4, &total);
-    if (emits) {
+    const uint32_t slot = block256_excl_scan_u32(c, sm4, &total);
+    const uint32_t local = block256_excl_scan_u32(c > 0 ? 1u : 0u, sm4b, &total);
+    if (c > 0) {
+        rec[(size_t)idx * REC_FLOATS + 2] = __uint_as_float(idx_block_offs[blockIdx.x] + slot);
         const uint32_t dst = vis_block_offs[blockIdx.x] + local;
         keys_out[dst] = depth_keys[idx];
         idx_out[dst] = (uint32_t)idx;
     }
 }
-void launch_compact_keys(int P, const uint32_t* tiles_touched, const uint32_t* depth_keys, const uint32_t* vis_block_offs,
-                         uint32_t* keys_out, uint32_t* idx_out, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(compact_keys_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_touched, depth_keys, vis_block_offs,
-                       keys_out, idx_out);
+void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec,
+                              const uint32_t* depth_keys, const uint32_t* vis_block_offs, uint32_t* keys_out,
+                              uint32_t* idx_out, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(slots_and_compact_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_touched, idx_block_offs, rec,
+                       depth_keys, vis_block_offs, keys_out, idx_out);
 }
 
-void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,
-                 const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
-                 hipStream_t s) {
-    hipLaunchKernelGGL(emit_kernel, dim3(nblocks), dim3(256), 0, s, P, tiles_x, tiles_y, gidx_sorted, tiles_touched,
-                       block_offs, radii, rec, entries);
+void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
+                        const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
+                        uint32_t* zero_ptr, int zero_words, hipStream_t s) {
+    // total[0] = instances binned, total[1] = the reference's num_rendered, total[2] = emitting Gaussians
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
+                       vis_block_sums, vis_block_offs, ref_block_sums, total, total + 2, zero_ptr, zero_words,
+                       (const uint32_t*)nullptr);
+}
+
+void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
+                 int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
+                 uint8_t* qhit, hipStream_t s) {
+    if (R_b == 0) return;
+    hipLaunchKernelGGL(emit_kernel, dim3((R_b + EMIT_SLOTS - 1) / EMIT_SLOTS), dim3(256), 0, s, V, R_b, tiles_x, tiles_y,
+                       gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit);
 }
 
 // rasterizer_impl.cu:116-138 on the packed entries (ranges pre-zeroed by the caller, :311)

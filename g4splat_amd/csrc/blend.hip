@@ -250,16 +250,31 @@ struct BwdPixel {
     uint32_t last_c, median_c;
     float dpx0, dpx1, dpx2, dL_ddepth, dL_daccum, dn0, dn1, dn2, dL_dmedian;
     // running state (back to front)
-    float T, last_alpha, last_v, V_rec, last_dL_dT;
+    float T, V_rec, last_dL_dT;
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// waves_per_eu(3): 168 VGPRs instead of the 171 the allocator would take -> 3 resident waves per SIMD instead of 2
-// (two 4-byte spills land in the per-batch prologue, not in the entry loop); measured 1.86 -> 1.51 ms on S3.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[BLEND_QUADS][BWD_BATCH];  // the culling quads are not needed here
-    __shared__ uint32_t s_slot[BWD_BATCH];
+// Occupancy is what this kernel responds to: at 158 VGPRs three waves fit a SIMD, at <= 128 four
+// do.  Of the 20 per-pixel values a lane carries for each of its four pixels, six are read once per visit (or
+// less) and never written: the three distortion constants, the background term, the median position and its
+// cotangent.  They are parked in LDS (24 B per pixel, read back with one ds_read_b128 per visit plus one
+// ds_read_b64 under the median branch), and the V_rec recurrence is advanced at the end of a visit instead of at the
+// start of the next one (two more registers per pixel).  That is 128 VGPRs with one 4-byte spill in the per-batch
+// prologue.  LDS then decides the occupancy: 16 single-wave workgroups per CU need <= 10 240 B each, which is why this
+// kernel stages 48 list entries per batch (3 840 B + 192 B slots + 6 144 B parked = 10 176 B).  Measured on S3:
+// 1.106 -> 1.046 ms; with 64-entry batches (14 workgroups per CU) it was slower than three waves (1.135 ms).
+constexpr int BWD1_BATCH = 48;  // list entries staged per batch by the one-wave kernel (see above)
+struct BwdPixelLite {  // what stays in registers per pixel; the rest of BwdPixel is parked in LDS
+    uint32_t last_c;
+    float dpx0, dpx1, dpx2, dL_ddepth, dL_daccum, dn0, dn1, dn2;
+    float T, V_rec, last_dL_dT;
+};
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_bwd_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[BLEND_QUADS][BWD1_BATCH];  // the culling quads are not needed here
+    __shared__ uint32_t s_slot[BWD1_BATCH];
+    __shared__ float4 s_cst[256];   // per pixel (quadrant * 64 + lane): A2, D2, C2, nTfbg
+    __shared__ float2 s_med[256];   // per pixel: bits(median_c), dL_dmedian
 
     const int tile = (int)a.tile_order[blockIdx.x];
     const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
@@ -273,13 +288,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int tx0 = tile_x * TILE, ty0 = tile_y * TILE;
     const int px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
-    BwdPixel p[4];
+    BwdPixelLite p[4];
     uint32_t max_last = 0, max_median = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
-        BwdPixel& x = p[q];
-        x = BwdPixel{};
+        BwdPixelLite& x = p[q];
+        x = BwdPixelLite{};
+        uint32_t median_c = 0; float dL_dmedian = 0;
         float T_final = 0, final_D = 0, final_D2 = 0, dL_dreg = 0;
         if (px < a.W && py < a.H) {
             const size_t pix_id = (size_t)a.W * py + px;
@@ -287,7 +303,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             final_D = a.final_T[pix_id + N];
             final_D2 = a.final_T[pix_id + 2 * N];
             x.last_c = a.n_contrib[pix_id];
-            x.median_c = a.n_contrib[pix_id + N];
+            median_c = a.n_contrib[pix_id + N];
             x.dpx0 = a.dL_dpix[pix_id];
             x.dpx1 = a.dL_dpix[pix_id + N];
             x.dpx2 = a.dL_dpix[pix_id + 2 * N];
@@ -296,16 +312,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
             x.dn0 = a.dL_depths[pix_id + 2 * N];
             x.dn1 = a.dL_depths[pix_id + 3 * N];
             x.dn2 = a.dL_depths[pix_id + 4 * N];
-            x.dL_dmedian = a.dL_depths[pix_id + 5 * N];
+            dL_dmedian = a.dL_depths[pix_id + 5 * N];
             dL_dreg = a.dL_depths[pix_id + 6 * N];
         }
-        x.A2 = (1 - T_final) * dL_dreg;
-        x.D2 = 2.0f * final_D * dL_dreg;
-        x.C2 = final_D2 * dL_dreg;
-        x.nTfbg = -T_final * ((bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2);
+        s_cst[q * 64 + lane] = make_float4((1 - T_final) * dL_dreg, 2.0f * final_D * dL_dreg, final_D2 * dL_dreg,
+                                           -T_final * ((bg0 * x.dpx0 + bg1 * x.dpx1) + bg2 * x.dpx2));
+        s_med[q * 64 + lane] = make_float2(__uint_as_float(median_c), dL_dmedian);
         x.T = T_final;
         max_last = max(max_last, x.last_c);  // pixels outside the image keep last_c = 0: never active
-        max_median = max(max_median, x.median_c);
+        max_median = max(max_median, median_c);
     }
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m = mscale - dmd_k / depth, dm/ddepth = dmd_k / depth^2
@@ -323,8 +338,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     // (records of instances that receive no contribution are never written; rec_flag tells the fold which are)
 
     // batches from the back of the live range; lane t stages list position hi-1-t
-    for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
-        const int m = imin_(BWD_BATCH, hi);
+    for (int hi = n_live; hi > 0; hi -= BWD1_BATCH) {
+        const int m = imin_(BWD1_BATCH, hi);
         __syncthreads();
         // bit q of qmask: some pixel of quadrant q blended the entry this lane stages -- recorded by
         // the forward (qhit).  A pixel is active here iff it blended the entry there (same eval, and
@@ -373,7 +388,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!((qm >> q) & 1u)) continue;  // scalar branch
-                BwdPixel& x = p[q];
+                BwdPixelLite& x = p[q];
+                const float4 cst = s_cst[q * 64 + lane];
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
                 bool act = pos < x.last_c;
@@ -391,9 +407,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     const float v = fmaf(q4.y, x.dpx0, fmaf(q4.z, x.dpx1, q4.w * x.dpx2)) +
                                     fmaf(c_d, x.dL_ddepth, x.dL_daccum) +
                                     fmaf(q1.x, x.dn0, fmaf(q1.y, x.dn1, q1.z * x.dn2));
-                    x.V_rec = fmaf(x.last_alpha, x.last_v - x.V_rec, x.V_rec);  // a v + (1 - a) V_rec
-                    x.last_v = v;
-                    float dL_dalpha = v - x.V_rec;
+                    // V_rec <- a v + (1 - a) V_rec is applied right here, for the next (shallower) entry: the same
+                    // operation on the same operands as the reference's deferred update (backward.cu:328), minus the
+                    // two registers per pixel that would carry last_alpha / last_v across the visit
+                    const float v_minus_rec = v - x.V_rec;
+                    float dL_dalpha = v_minus_rec;
+                    x.V_rec = fmaf(alpha, v_minus_rec, x.V_rec);
                     gp[0].x = fmaf(w, x.dpx0, gp[0].x);
                     gp[0].y = fmaf(w, x.dpx1, gp[0].y);
                     gp[1].x = fmaf(w, x.dpx2, gp[1].x);
@@ -405,17 +424,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
                     float dL_dz = 0.0f;
-                    if (pos < tile_max_median) dL_dz = (pos + 1 == x.median_c) ? x.dL_dmedian : 0.0f;  // scalar branch
-                    const float dL_dweight = fmaf(m_d, fmaf(m_d, x.A2, -x.D2), x.C2);
+                    if (pos < tile_max_median) { const float2 md = s_med[q * 64 + lane]; dL_dz = (pos + 1 == __float_as_uint(md.x)) ? md.y : 0.0f; }  // scalar branch
+                    const float dL_dweight = fmaf(m_d, fmaf(m_d, cst.x, -cst.y), cst.z);
                     const float dwt = dL_dweight - x.last_dL_dT;
                     dL_dalpha += dwt;
                     x.last_dL_dT = fmaf(alpha, dwt, x.last_dL_dT);  // a dL_dweight + (1 - a) last_dL_dT
-                    const float dL_dmd = w * fmaf(m_d + m_d, x.A2, -x.D2);
+                    const float dL_dmd = w * fmaf(m_d + m_d, cst.x, -cst.y);
                     dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
 
                     dL_dalpha *= T;
-                    x.last_alpha = alpha;
-                    dL_dalpha = fmaf(x.nTfbg, inv1ma, dL_dalpha);
+                    dL_dalpha = fmaf(cst.w, inv1ma, dL_dalpha);
                     const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
 
@@ -599,9 +617,9 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     const float v = fmaf(q4.y, x.dpx0, fmaf(q4.z, x.dpx1, q4.w * x.dpx2)) +
                                     fmaf(c_d, x.dL_ddepth, x.dL_daccum) +
                                     fmaf(q1.x, x.dn0, fmaf(q1.y, x.dn1, q1.z * x.dn2));
-                    x.V_rec = fmaf(x.last_alpha, x.last_v - x.V_rec, x.V_rec);
-                    x.last_v = v;
-                    float dL_dalpha = v - x.V_rec;
+                    const float v_minus_rec = v - x.V_rec;
+                    float dL_dalpha = v_minus_rec;
+                    x.V_rec = fmaf(alpha, v_minus_rec, x.V_rec);
                     g[0] = fmaf(w, x.dpx0, g[0]); g[1] = fmaf(w, x.dpx1, g[1]); g[2] = fmaf(w, x.dpx2, g[2]);
                     g[3] = fmaf(w, x.dn0, g[3]); g[4] = fmaf(w, x.dn1, g[4]); g[5] = fmaf(w, x.dn2, g[5]);
                     const float inv_cd = fast_rcp(c_d);
@@ -616,7 +634,6 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     const float dL_dmd = w * fmaf(m_d + m_d, x.A2, -x.D2);
                     dL_dz = fmaf(dL_dmd, dmd_dd, dL_dz);
                     dL_dalpha *= T;
-                    x.last_alpha = alpha;
                     dL_dalpha = fmaf(x.nTfbg, inv1ma, dL_dalpha);
                     const float dL_dG = q1.w * dL_dalpha;
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);

@@ -155,27 +155,26 @@ int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
                         uint32_t* bin_total, hipStream_t s);
 
-// Exclusive scan (in depth order) of tiles_touched; total written to *total (device).
-// total[0] = instances binned, total[1] = sum of ref_block_sums (the reference's num_rendered).
+// Exclusive scan (in depth order) of tiles_touched: block_offs[r >> 8] + rank_local[r] = first output slot of depth
+// rank r; total[0] = instances binned.
 void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles_touched, uint32_t* block_sums,
-                       uint32_t* block_offs, const uint32_t* ref_block_sums, uint32_t* total, int nblocks,
-                       hipStream_t s, const uint32_t* d_n = nullptr);
-// Gradient-record slots in INDEX order: rec[idx].inst_off = exclusive scan of tiles_touched over idx
-// (so that the per-Gaussian fold of the backward streams the record buffer sequentially).
-void launch_grad_slots(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec, int nblocks,
-                       hipStream_t s);
+                       uint32_t* block_offs, uint32_t* rank_local, uint32_t* total, int nblocks, hipStream_t s,
+                       const uint32_t* d_n = nullptr);
 // Totals and block offsets that only need the preprocess' per-block partial sums (no sort): exclusive scans of
 // idx_block_sums and vis_block_sums; total[0] = instances binned, total[1] = the reference's num_rendered,
-// total[2] = number of emitting Gaussians.
+// total[2] = number of emitting Gaussians.  Also clears zero_words 32-bit words at zero_ptr (the tile ranges).
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
-                        hipStream_t s);
-// Stable compaction (index order) of the emitting Gaussians' (depth key, index) pairs.
-void launch_compact_keys(int P, const uint32_t* tiles_touched, const uint32_t* depth_keys, const uint32_t* vis_block_offs,
-                         uint32_t* keys_out, uint32_t* idx_out, int nblocks, hipStream_t s);
-void launch_emit(int P, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* tiles_touched,
-                 const uint32_t* block_offs, const int* radii, float* rec, uint64_t* entries, int nblocks,
-                 hipStream_t s);
+                        uint32_t* zero_ptr, int zero_words, hipStream_t s);
+// Index-order pass: gradient-record slots (rec[idx].inst_off = exclusive scan of tiles_touched over idx) and the
+// stable compaction of the emitting Gaussians' (depth key, index) pairs.
+void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec,
+                              const uint32_t* depth_keys, const uint32_t* vis_block_offs, uint32_t* keys_out,
+                              uint32_t* idx_out, int nblocks, hipStream_t s);
+// Instances in depth order, R_b of them; also clears qhit[0, R_b).
+void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
+                 int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
+                 uint8_t* qhit, hipStream_t s);
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s);
 // Longest-list-first processing order of the tiles (work balance of the blend kernels).
 void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s);

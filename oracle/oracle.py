@@ -159,12 +159,18 @@ def instance_flags(o):
     return flags[:R]
 
 
-def instance_flags(o):
-    """uint8[R]: 1 where the (tile, Gaussian) instance of Oracle `o` has a pixel passing the alpha test."""
-    R = o._fw["R"]
-    flags = np.zeros((max(R, 1),), np.uint8)
-    lib().oracle_instance_flags(o._s, _ptr(flags))
-    return flags[:R]
+def pixel_margins(o):
+    """float32[3, H*W]: per pixel, the smallest relative distance to a threshold met by each kind of discrete
+    decision of the forward loop (0: skip a splat -- alpha vs 1/255, depth vs near; 1: stop the pixel -- T(1-alpha)
+    vs 1e-4; 2: median depth -- T vs 0.5).  See oracle_pixel_margins in surfel_oracle.c."""
+    fw = o._fw
+    N = fw["H"] * fw["W"]
+    out = np.full((3, N), np.finfo(np.float32).max, np.float32)
+    if fw["P"] == 0:
+        return out
+    tm = fw["a"]["transMat"]
+    lib().oracle_pixel_margins(o._s, _ptr(tm if tm is not None and tm.size else None), _ptr(out))
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
@@ -181,6 +187,15 @@ def distCUDA2(points):
     p = _f32(points)
     out = np.zeros((p.shape[0],), np.float32)
     lib().oracle_knn(ctypes.c_int(p.shape[0]), _ptr(p), _ptr(out))
+    return out
+
+
+def distCUDA2_queries(points, queries):
+    """distCUDA2 restricted to the rows `queries` (all points are neighbour candidates): brute force, O(len(queries) P)."""
+    p = _f32(points)
+    q = np.ascontiguousarray(np.asarray(queries, dtype=np.int32))
+    out = np.zeros((q.shape[0],), np.float32)
+    lib().oracle_knn_queries(ctypes.c_int(p.shape[0]), _ptr(p), ctypes.c_int(q.shape[0]), ctypes.c_void_p(q.ctypes.data), _ptr(out))
     return out
 
 

@@ -1,14 +1,14 @@
 """TEST INFRASTRUCTURE ONLY -- plain-torch restatement of the map post-processing of the reference's
 `render()`; the checker for g4splat_amd/render_maps.py (HIP).  Never imported by the product.
 
-PARITY UNPINNED for the same reason as the rest of oracle/: the reference's own functions cannot be
-imported here (utils/point_utils.py imports cv2 and hard-codes .cuda()); this file follows them line
-by line instead:
+PINNED: tests/golden/render_tail.npz holds the outputs AND the autograd gradient of the reference's own
+`render()` (2d-gaussian-splatting/gaussian_renderer/__init__.py:19-166, which calls utils/point_utils.py:9-37), run on
+the CPU of the build container with only the compiled rasterizer replaced by a stand-in that returns seeded tensors
+(tests/golden/make_golden_maps.py); tests/test_oracle_golden.py checks this file against it, tests/
+test_gpu_render_maps.py checks the HIP kernels against it.  This file follows the reference line by line:
     depths_to_points   2d-gaussian-splatting/utils/point_utils.py:9-24
     depth_to_normal    2d-gaussian-splatting/utils/point_utils.py:26-37
     render_maps        2d-gaussian-splatting/gaussian_renderer/__init__.py:117-164
-The camera helpers it is fed with (getWorld2View2, getProjectionMatrix) ARE the reference's, pinned by
-tests/golden/camera.npz.
 """
 import torch
 

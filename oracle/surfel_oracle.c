@@ -952,3 +952,80 @@ void oracle_instance_flags(const OracleState *s, uint8_t *flags /*R*/) {
         }
     }
 }
+
+/* Decision margins per pixel (test infrastructure, not part of the restatement).
+ *
+ * The per-pixel loop of forward.cu:346-433 takes three kinds of discrete decisions on computed floats:
+ *   (0) skip the splat:  alpha < 1/255 (forward.cu:389) or depth < near (forward.cu:379)
+ *   (1) stop the pixel:  T (1 - alpha) < 1e-4 (forward.cu:394-399)
+ *   (2) median depth:    T > 0.5 (forward.cu:412-417)
+ * Any two correct single-precision evaluations of the same formulas (this file with libm's expf and IEEE
+ * division; the HIP kernels with v_exp_f32 / v_rcp_f32; the CUDA reference with its own expf) differ by ~1e-6
+ * relative in alpha and T, so a pixel whose value sits within that distance of a threshold may legitimately
+ * fall on either side.  This function re-walks every pixel's list exactly like render_fwd and records, per
+ * decision kind, the smallest relative distance |value - threshold| / threshold met on the way:
+ * out[k * N + pix], k = 0..2 (FLT_MAX if the decision never came up).  Parity tests use it to PROVE that every
+ * pixel whose outputs differ from the HIP path beyond the tolerance sits on such a threshold
+ * (tests/common.py::explain_mismatches). */
+void oracle_pixel_margins(const OracleState *s, const float *transMats, float *out /*3N*/) {
+    const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+    const size_t N = (size_t)W * H;
+    if (!transMats) transMats = s->transMat;
+    for (size_t i = 0; i < 3 * N; i++) out[i] = FLT_MAX;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++) for (int lx = 0; lx < BLOCK_X; lx++) {
+            int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+            if (px >= W || py >= H) continue;
+            size_t pix_id = (size_t)W * py + px;
+            float pxf = (float)px, pyf = (float)py;
+            float T = 1.0f;
+            float m0 = FLT_MAX, m1 = FLT_MAX, m2 = FLT_MAX;
+            for (uint32_t i = r0; i < r1; i++) {
+                uint32_t id = s->point_list[i];
+                const float *no = s->normal_opacity + 4 * (size_t)id;
+                PairEval e;
+                memset(&e, 0, sizeof e);
+                int ok = eval_pair(pxf, pyf, s->means2D + 2 * (size_t)id, transMats + 9 * (size_t)id, no[3], &e);
+                if (e.pz != 0.0f) {  /* p.z == 0 is exact on every side (same fma sequence) */
+                    float md = fabsf(e.depth - near_n) / near_n;
+                    if (md < m0) m0 = md;
+                    if (e.depth >= near_n) {
+                        float a = no[3] * expf(-0.5f * fminf(e.rho3d, e.rho2d));
+                        float ma = fabsf(a - 1.0f / 255.0f) * 255.0f;
+                        if (ma < m0) m0 = ma;
+                    }
+                }
+                if (!ok) continue;
+                float test_T = T * (1 - e.alpha);
+                float mt = fabsf(test_T - 0.0001f) / 0.0001f;
+                if (mt < m1) m1 = mt;
+                if (test_T < 0.0001f) break;
+                float mh = fabsf(T - 0.5f) / 0.5f;
+                if (mh < m2) m2 = mh;
+                T = test_T;
+            }
+            out[pix_id] = m0; out[pix_id + N] = m1; out[pix_id + 2 * N] = m2;
+        }
+    }
+}
+
+/* knn/simple_knn.cu:131-183 for a SUBSET of query points (all P points are candidates): lets the parity
+ * test check distCUDA2 at 3e5 .. 1.5e6 points against the brute-force definition on a few thousand queries. */
+void oracle_knn_queries(int P, const float *points, int nq, const int *queries, float *meanDists /*nq*/) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int qi = 0; qi < nq; qi++) {
+        int i = queries[qi];
+        float best[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+        float rx = points[3 * i], ry = points[3 * i + 1], rz = points[3 * i + 2];
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            float dx = points[3 * j] - rx, dy = points[3 * j + 1] - ry, dz = points[3 * j + 2] - rz;
+            float dist = dx * dx + dy * dy + dz * dz;
+            for (int k = 0; k < 3; k++) if (best[k] > dist) { float t = best[k]; best[k] = dist; dist = t; }
+        }
+        meanDists[qi] = (best[0] + best[1] + best[2]) / 3.0f;
+    }
+}

@@ -94,3 +94,120 @@ def rel_err(a, b):
     """max |a-b| over max |b| (tensor-level relative error; SURVEY 8(d) 'grad rel-error')."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)) if b.size else 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Parity bars and the threshold-margin proof.
+#
+# CONTRACT bars (BASELINE.json north_star): outputs <= 1e-4 abs, gradients <= 1e-3 rel (tensor-level).
+# GUARD bars: ~10x what the HIP path actually achieves against the oracle (measured on MI355X with
+# tools/parity_report.py, profiles/r02_parity_report.txt): they are what the tests assert, so that a regression
+# of one order of magnitude is caught long before the contract is at risk.
+#
+# A pixel or gradient row outside a bar is accepted ONLY if it is *explained*: the oracle reports, per pixel,
+# how close each discrete decision of the forward loop (alpha >= 1/255, depth >= near, T(1-alpha) >= 1e-4,
+# T > 0.5) came to its threshold (oracle.pixel_margins).  Any two correct single-precision evaluations differ
+# by ~1e-6 relative there, so within MARGIN either side is a correct answer.  Everything else fails the test.
+OUT_ATOL = 1e-4          # contract
+GRAD_RTOL = 1e-3         # contract, max|a-b| / max|b| per tensor
+OUT_ATOL_GUARD = 2e-5    # guard: measured <= 2.9e-6 on S1..S5 and 60 fuzz scenes (worst map: the depth sum, values up to ~6)
+GRAD_RTOL_GUARD = 1e-4   # guard: measured <= 1.1e-5 tensor-level (typically 1e-6)
+ROW_RTOL_GUARD = 1e-2    # guard, row-level (measured <= 8.6e-4): |a-b|_row,inf / |b|_row,inf for rows above ROW_FLOOR of the tensor's max
+ROW_FLOOR = 1e-3
+MARGIN = 1e-5            # relative distance to a decision threshold below which either side is correct
+
+
+def _last_and_median_ids(n_contrib, ranges, ids, W, H):
+    """Per pixel: Gaussian id of the last contributor and of the median contributor (-1 = none).  List positions
+    differ between the two sides (the HIP lists are culled subsequences of the reference lists), ids do not."""
+    ty, tx = np.mgrid[0:H, 0:W]
+    tile = ((ty // 16) * ((W + 15) // 16) + tx // 16).reshape(-1)
+    out = []
+    for row in (0, 1):
+        c = n_contrib.reshape(2, -1)[row].astype(np.int64)
+        pos = ranges[tile, 0].astype(np.int64) + c - 1
+        out.append(np.where(c > 0, ids[np.clip(pos, 0, max(len(ids) - 1, 0))].astype(np.int64) if len(ids) else -1, -1))
+    return out
+
+
+def parity_report(h, o, inp, oracle_mod):
+    """Compares a HIP result `h` (run_hip) with the oracle's `o` (run_oracle) and classifies every mismatch.
+    Returns a dict of measured errors (over the unexplained part) and of the explained sets."""
+    W, H = inp["W"], inp["H"]
+    N = W * H
+    orc = o["oracle"]
+    rep = dict(N=N, R=int(o["R"]))
+    margins = oracle_mod.pixel_margins(orc)          # [3, N]
+    suspect = margins.min(axis=0) < MARGIN           # either side of some threshold is a correct answer here
+    rep["suspect_pixels"] = int(suspect.sum())
+    # ---- outputs
+    diffs = np.concatenate([np.abs(h["color"] - o["color"]), np.abs(h["others"] - o["others"])], 0).reshape(10, N)
+    dmax = diffs.max(axis=0)
+    rep["out_err_unexplained"] = float(dmax[~suspect].max()) if (~suspect).any() else 0.0
+    rep["out_err_per_map_unexplained"] = [float(d[~suspect].max()) if (~suspect).any() else 0.0 for d in diffs]
+    rep["out_err_all"] = float(dmax.max()) if N else 0.0
+    # ---- contributor bookkeeping, as Gaussian ids
+    st = hip_state(h, inp) if o["R"] > 0 else None
+    if st is not None:
+        hid = _last_and_median_ids(st["n_contrib"], st["ranges"], (st["entries"] & np.uint64(0xFFFFFFFF)).astype(np.uint32), W, H)
+        oid = _last_and_median_ids(orc.state("n_contrib"), orc.state("ranges"), orc.state("point_list"), W, H)
+        id_bad = (hid[0] != oid[0]) | (hid[1] != oid[1])
+    else:
+        id_bad = np.zeros(N, bool)
+    rep["id_mismatch"] = int(id_bad.sum())
+    rep["id_mismatch_unexplained"] = int((id_bad & ~suspect).sum())
+    # flipped pixels: on a threshold AND visibly different
+    flipped = suspect & ((dmax > OUT_ATOL_GUARD) | id_bad)
+    rep["flipped_pixels"] = int(flipped.sum())
+    rep["flipped_worst"] = float(dmax[flipped].max()) if flipped.any() else 0.0
+    rep["flipped_max_margin"] = float(margins.min(axis=0)[flipped].max()) if flipped.any() else 0.0
+    # ---- gradients: a flipped pixel moves O(|cotangent|) between the Gaussians of its tile's list
+    if "grads" in h and "grads" in o:
+        P = inp["means3D"].shape[0]
+        explained = np.zeros(P, bool)
+        if flipped.any():
+            tiles_x = (W + 15) // 16
+            fy, fx = np.divmod(np.nonzero(flipped)[0], W)
+            olist, orng = orc.state("point_list"), orc.state("ranges")
+            for t in np.unique((fy // 16) * tiles_x + fx // 16):
+                explained[olist[orng[t, 0]:orng[t, 1]]] = True
+        rep["explained_rows"] = int(explained.sum())
+        g = {}
+        for name in ("means3D", "scales", "rotations", "opacity", "sh", "colors", "transMat", "means2D"):
+            a, b = h["grads"][name], o["grads"][name]
+            if b.size == 0:
+                assert a.size == 0, name
+                continue
+            assert a.shape == b.shape, name
+            a, b = a.astype(np.float64).reshape(len(a), -1), b.astype(np.float64).reshape(len(b), -1)
+            scale = np.abs(b).max() + 1e-30
+            row_err = np.abs(a - b).max(axis=1)
+            row_mag = np.abs(b).max(axis=1)
+            un = ~explained
+            big = un & (row_mag > ROW_FLOOR * scale)
+            g[name] = dict(rel_unexplained=float(row_err[un].max() / scale) if un.any() else 0.0,
+                           rel_all=float(row_err.max() / scale),
+                           row_rel_unexplained=float((row_err[big] / row_mag[big]).max()) if big.any() else 0.0,
+                           rows_beyond_contract=int((row_err > GRAD_RTOL * scale).sum()),
+                           rows_beyond_contract_unexplained=int(((row_err > GRAD_RTOL * scale) & un).sum()),
+                           l2=float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)))
+        rep["grads"] = g
+    return rep
+
+
+def assert_parity(h, o, inp, oracle_mod, tag="", out_atol=OUT_ATOL_GUARD, grad_rtol=GRAD_RTOL_GUARD,
+                  row_rtol=ROW_RTOL_GUARD, max_flipped_frac=3e-5):
+    """The parity gate of the GPU tests: exact integers, guard bars on everything that is not explained by a
+    decision threshold, and a cap on how much may be explained away."""
+    assert h["R"] == o["R"], tag
+    np.testing.assert_array_equal(h["radii"], o["radii"], err_msg=tag)
+    rep = parity_report(h, o, inp, oracle_mod)
+    N = rep["N"]
+    assert rep["out_err_unexplained"] <= out_atol, (tag, "output beyond the bar on a pixel that is on no threshold", rep)
+    assert rep["id_mismatch_unexplained"] == 0, (tag, "contributor mismatch on a pixel that is on no threshold", rep)
+    assert rep["flipped_pixels"] <= max(2, max_flipped_frac * N), (tag, "too many threshold flips", rep)
+    for name, g in rep.get("grads", {}).items():
+        assert g["rel_unexplained"] <= grad_rtol, (tag, name, g)
+        assert g["row_rel_unexplained"] <= row_rtol, (tag, name, g)
+        assert g["l2"] <= GRAD_RTOL, (tag, name, g)
+    return rep

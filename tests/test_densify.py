@@ -179,3 +179,41 @@ def test_schedule_checkpoint_and_helpers(tmp_path):
     assert not any(p.requires_grad for p in m.parameters())
     m.set_mip_filter(True)
     assert m.use_mip_filter
+
+
+def test_replay_of_the_reference_gaussian_model():
+    """tests/golden/densify.npz was written by running the REFERENCE's GaussianModel (scene/gaussian_model.py) on the CPU
+    of the build container through create_from_parameters -> training_setup -> 3 Adam steps -> 4 x
+    add_densification_stats -> densify_and_prune (clone, split with its seeded torch.normal draw, prune, with and
+    without a screen-size limit, NaN statistics) -> reset_opacity (tests/golden/make_golden_densify.py).  The same
+    sequence on this repo's GaussianModel / densify.py must give the same parameters, the same Adam moments and the
+    same statistics after every stage -- bit for bit: same torch ops on the same CPU generator."""
+    import os
+    import sys
+    import types
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold_dir)
+    try:
+        import make_golden_densify as mg
+    finally:
+        sys.path.remove(gold_dir)
+    z = np.load(os.path.join(gold_dir, "densify.npz"))
+    inp = dict(vs_grad=[z[f"in_vs_grad_{i}"] for i in range(4)], vs_filter=[z[f"in_vs_filter_{i}"] for i in range(4)],
+               max_radii=z["in_max_radii"])
+    gm = GaussianModel(3)
+    gm.create_from_parameters(torch.tensor(z["in_means"]), torch.tensor(z["in_scales"]), torch.tensor(z["in_quats"]),
+                              torch.tensor(z["in_colors"]), 1.0)
+    with torch.no_grad():
+        gm._opacity.copy_(torch.tensor(z["in_opacity_raw"]))
+        gm._features_rest.copy_(torch.tensor(z["in_f_rest"]))
+    gm.training_setup(types.SimpleNamespace(**mg.ARGS), fused=False)
+    out = {}
+    mg.snapshot(gm, "initial", out)
+    mg.drive(gm, inp, out, lambda m: [g["params"][0] for g in m.optimizer.param_groups])
+    keys = [k for k in z.files if not k.startswith("in_")]
+    assert len(keys) > 60
+    for k in keys:
+        assert k in out, k
+        assert out[k].shape == z[k].shape, (k, out[k].shape, z[k].shape)
+        np.testing.assert_array_equal(out[k], z[k], err_msg=k)
+    assert z["after_densify_xyz"].shape[0] > z["initial_xyz"].shape[0]  # it did clone / split

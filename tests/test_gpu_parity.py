@@ -1,34 +1,17 @@
 """HIP path vs CPU oracle on identical seeded inputs, through the C ABI (`_C` front-end).
 
-Tolerances (BASELINE.json north_star): outputs <= 1e-4 abs, gradients <= 1e-3 rel
-(rel = max|a-b| / max|b| per gradient tensor).  Integer/index results (radii, num_rendered,
-per-tile sorted lists, tile ranges, contributor counts) must be identical."""
+Contract (BASELINE.json north_star): outputs <= 1e-4 abs, gradients <= 1e-3 rel (max|a-b| / max|b| per gradient
+tensor).  What the tests ASSERT is tighter (tests/common.py): guard bars ~10x the measured error of the HIP path
+(outputs 2e-5, gradients 1e-4 tensor-level and 1e-2 row-level), and any pixel or gradient row beyond them must be
+*explained* by a discrete decision of the forward loop that sits within 1e-5 relative of its threshold in the oracle
+(`oracle.pixel_margins`) -- an unexplained mismatch fails, at any scene size.  Integer/index results (radii,
+num_rendered, per-tile sorted lists, tile ranges, contributor ids) must be identical."""
 import numpy as np
 import pytest
 
-from common import EMPTY, cotangents, hip_state, rel_err, run_hip, run_oracle, scene_inputs
+from common import EMPTY, assert_parity, cotangents, hip_state, run_hip, run_oracle, scene_inputs
 
 pytestmark = pytest.mark.gpu
-
-OUT_ATOL = 1e-4
-GRAD_RTOL = 1e-3
-
-
-def check_forward(h, o):
-    assert h["R"] == o["R"]
-    np.testing.assert_array_equal(h["radii"], o["radii"])
-    assert np.abs(h["color"] - o["color"]).max() <= OUT_ATOL
-    for c in range(7):
-        assert np.abs(h["others"][c] - o["others"][c]).max() <= OUT_ATOL, f"others[{c}]"
-
-
-def check_grads(h, o):
-    for name in ("means3D", "scales", "rotations", "opacity", "sh", "colors", "transMat", "means2D"):
-        if o["grads"][name].size == 0:
-            assert h["grads"][name].size == 0
-            continue
-        assert h["grads"][name].shape == o["grads"][name].shape, name
-        assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, name
 
 
 def hip_tile_lists(st):
@@ -87,13 +70,13 @@ def test_stages_match_oracle(hip_lib, oracle_mod):
     np.testing.assert_array_equal(st["depth_sorted"][:len(want)], want)
     kept, total = check_lists_against_oracle(st, orc, oracle_mod)
     assert kept == int(st["tiles_touched"].sum()) and total == o["R"]
-    assert np.abs(st["final_T"] - orc.state("final_T")).max() <= OUT_ATOL
+    assert np.abs(st["final_T"] - orc.state("final_T")).max() <= 2e-5
     # workgroup -> tile map: a permutation, longest lists first (4-entry buckets)
     order = st["tile_order"].astype(np.int64)
     assert np.array_equal(np.sort(order), np.arange(len(st["ranges"])))
     n = (st["ranges"][:, 1] - st["ranges"][:, 0])[order].astype(np.int64)
     assert np.all(np.diff(np.minimum(n >> 2, 2047)) <= 0)
-    check_forward(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 @pytest.mark.parametrize("D", [0, 1, 2, 3])
@@ -103,8 +86,7 @@ def test_config1_forward_backward(hip_lib, oracle_mod, D):
     g = cotangents(256, 256)
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 def test_ragged_image_and_scale_modifier(hip_lib, oracle_mod):
@@ -112,8 +94,7 @@ def test_ragged_image_and_scale_modifier(hip_lib, oracle_mod):
     g = cotangents(131, 250, seed=3)
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 def test_precomputed_colors_and_transmat(hip_lib, oracle_mod):
@@ -130,8 +111,7 @@ def test_precomputed_colors_and_transmat(hip_lib, oracle_mod):
     g = cotangents(96, 128, seed=8)
     o = run_oracle(oracle_mod, inp2, g)
     h = run_hip(inp2, g)
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp2, oracle_mod)
 
 
 def test_empty_and_all_culled(hip_lib, oracle_mod):
@@ -143,7 +123,7 @@ def test_empty_and_all_culled(hip_lib, oracle_mod):
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
     assert h["R"] == 0 and o["R"] == 0
-    check_forward(h, o)
+    assert_parity(h, o, inp, oracle_mod)
     for k, v in h["grads"].items():
         assert not np.any(v), k
     # P == 0 -> zero-filled outputs (rasterize_points.cu:85-99), no launch
@@ -171,8 +151,7 @@ def test_equal_depth_ties_and_tile_clipping(hip_lib, oracle_mod):
     h = run_hip(inp, g)
     st = hip_state(h, inp)
     check_lists_against_oracle(st, o["oracle"], oracle_mod)
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 def test_backward_is_deterministic(hip_lib):
@@ -279,72 +258,77 @@ def test_distCUDA2(hip_lib, oracle_mod, P):
     np.testing.assert_array_equal(got, want)
 
 
-def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys):
-    """bench.py's workload S3 at full size (1.5 M surfels, 1600x1200, SH degree 3) against the oracle directly
-    (its OpenMP loops take a few seconds on the GPU box's host cores).
-
-    Per-Gaussian results and the binning are exact at any size.  Per pixel, ~4e8 (pixel, splat) evaluations meet
-    three thresholds (alpha >= 1/255, T >= 1e-4, T > 0.5) with alpha known to ~1e-6 relative on either side
-    (v_rcp_f32 / v_exp_f32 here, libm there -- the CUDA reference's own exp differs from libm just the same), so a
-    handful of pixels per frame legitimately take the other side of a threshold; the bar at this size is therefore
-    statistical: all but <= 2e-5 of the pixels within 1e-4, all but <= 2e-5 of the contributor counts equal."""
+@pytest.mark.parametrize("P", [300_000, 1_500_000])
+def test_distCUDA2_at_scene_size(hip_lib, oracle_mod, P):
+    """distCUDA2 on the point sets of BASELINE configs 2 and 3 (surfels on the faces of the room box: the Morton
+    boxes of knn/simple_knn.cu:147-183 are flat and many -- ~300 / ~1 500 of them -- so the pruned search is exercised
+    for real) against the brute-force definition on 20 000 random query rows, exact equality."""
+    import torch
     from g4splat_amd import synthetic
-    P, W, H = 1_500_000, 1600, 1200
+    from g4splat_amd.simple_knn._C import distCUDA2
+    pts = synthetic.scene_room(P, seed=0).means3D.copy()
+    rng = np.random.default_rng(P)
+    dup = rng.choice(P, 64, replace=False)
+    pts[dup[:32]] = pts[dup[32:]]  # exact duplicates: distance 0 participates
+    q = np.unique(np.concatenate([rng.choice(P, 20_000, replace=False), dup])).astype(np.int32)
+    got = distCUDA2(torch.as_tensor(pts, device="cuda")).cpu().numpy()
+    want = oracle_mod.distCUDA2_queries(pts, q)
+    np.testing.assert_array_equal(got[q], want)
+    assert np.isfinite(got).all() and (got >= 0).all()
+
+
+def room_inputs(P, W, H, view, nviews, D=3, bg=(0.3, 0.1, 0.2)):
+    from g4splat_amd import synthetic
     scene = synthetic.scene_room(P, seed=0)
-    import os
-    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[int(os.environ.get("G4S_TEST_VIEW", "5"))]  # (other views: a manual sweep)
-    inp = dict(bg=np.array([0.3, 0.1, 0.2], np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
-               scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
-               view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
-               H=H, W=W, sh=scene.shs, D=3, campos=cam.camera_center)
-    gr = cotangents(H, W, seed=3)
+    cam = synthetic.room_cameras(nviews, W, H, fovx_deg=90.0)[view]
+    return dict(bg=np.array(bg, np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
+                scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
+                view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                H=H, W=W, sh=scene.shs, D=D, campos=cam.camera_center)
+
+
+def full_size_case(oracle_mod, capsys, tag, inp, seed=3):
+    """One BASELINE-size configuration against the oracle, with the threshold-margin proof: per-Gaussian results
+    and the binning exact; every pixel beyond the guard bar and every contributor-id mismatch must sit within 1e-5
+    (relative) of a decision threshold in the oracle; every gradient row beyond the guard bars must belong to the
+    tile list of such a pixel; the number of such pixels is capped at 3e-5 of the frame."""
+    gr = cotangents(inp["H"], inp["W"], seed=seed)
     o = run_oracle(oracle_mod, inp, gr)
     h = run_hip(inp, gr)
-    assert h["R"] == o["R"] and h["R"] > 4_000_000
-    np.testing.assert_array_equal(h["radii"], o["radii"])
-    N = W * H
-    bad = np.zeros((H, W), bool)
-    worst = {}
-    for name, a, b in [("color", h["color"], o["color"])] + [(f"others[{c}]", h["others"][c:c + 1], o["others"][c:c + 1])
-                                                             for c in range(7)]:
-        d = np.abs(a - b).max(axis=0)
-        bad |= d > OUT_ATOL
-        worst[name] = float(d.max())
-    # last contributor per pixel, as a Gaussian id (list positions differ: the HIP lists are culled subsequences)
-    st = hip_state(h, inp)
-    orc = o["oracle"]
-    ty, tx = np.mgrid[0:H, 0:W]
-    tile = ((ty // 16) * ((W + 15) // 16) + tx // 16).reshape(-1)
-
-    def last_id(n_contrib, ranges, ids):
-        last = n_contrib.reshape(2, -1)[0].astype(np.int64)
-        pos = ranges[tile, 0].astype(np.int64) + last - 1
-        return np.where(last > 0, ids[np.clip(pos, 0, len(ids) - 1)].astype(np.int64), -1)
-
-    hid = last_id(st["n_contrib"], st["ranges"], (st["entries"] & np.uint64(0xFFFFFFFF)).astype(np.uint32))
-    oid = last_id(orc.state("n_contrib"), orc.state("ranges"), orc.state("point_list"))
-    nc_bad = hid != oid
-    with capsys.disabled():
-        print(f"\nS3 full size: {int(bad.sum())} of {N} pixels beyond 1e-4 (worst per map {worst}), "
-              f"{int(nc_bad.sum())} contributor-count mismatches")
-    assert bad.sum() <= 2e-5 * N
-    assert nc_bad.sum() <= 2e-5 * N
+    rep = assert_parity(h, o, inp, oracle_mod, tag=tag)
     assert np.median(np.abs(h["color"] - o["color"])) <= 1e-6
-    # gradients: a flipped median / alpha decision moves an O(|cotangent|) term from one Gaussian to another, so
-    # the bar is again statistical -- rows beyond 1e-3 of the tensor's largest entry are as rare as the pixel
-    # flips, and the tensors agree to 1e-3 in the L2 sense (measured ~1e-4)
-    V = int((o["radii"] > 0).sum())
-    rep = {}
-    for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
-        a, b = h["grads"][name].astype(np.float64), o["grads"][name].astype(np.float64)
-        a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
-        rows = (np.abs(a - b).max(axis=1) > GRAD_RTOL * np.abs(b).max()).sum()
-        l2 = np.linalg.norm(a - b) / np.linalg.norm(b)
-        rep[name] = (int(rows), float(l2))
-        assert rows <= max(4, 1e-4 * V), (name, rows)
-        assert l2 <= GRAD_RTOL, (name, l2)
     with capsys.disabled():
-        print("gradient rows beyond 1e-3 / relative L2 error:", rep)
+        g = rep["grads"]
+        print(f"\n{tag}: R={rep['R']}, {rep['suspect_pixels']} of {rep['N']} pixels within 1e-5 of a threshold, "
+              f"{rep['flipped_pixels']} of them flipped (worst output difference {rep['flipped_worst']:.3g}); elsewhere "
+              f"outputs <= {rep['out_err_unexplained']:.2e}, gradients <= "
+              f"{max(v['rel_unexplained'] for v in g.values()):.2e} (tensor) / "
+              f"{max(v['row_rel_unexplained'] for v in g.values()):.2e} (row), {rep['explained_rows']} rows explained")
+    return rep, h, o
+
+
+def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys):
+    """BASELINE config 3 (bench.py's workload S3) at full size: 1.5 M surfels, 1600x1200, SH degree 3 (the oracle's
+    OpenMP loops take a few seconds on the GPU box's host cores).  G4S_TEST_VIEW picks another of the eight views."""
+    import os
+    view = int(os.environ.get("G4S_TEST_VIEW", "5"))
+    rep, h, o = full_size_case(oracle_mod, capsys, f"S3 view {view}", room_inputs(1_500_000, 1600, 1200, view, 8))
+    assert rep["R"] > 4_000_000
+
+
+@pytest.mark.parametrize("view,D", [(0, 3), (2, 0), (4, 3)])
+def test_config2_room_views(hip_lib, oracle_mod, capsys, view, D):
+    """BASELINE config 2 stand-in (S2): 300 k surfels, 1200x680, three of the five views, SH degree 0 and 3."""
+    rep, h, o = full_size_case(oracle_mod, capsys, f"S2 view {view} D={D}", room_inputs(300_000, 1200, 680, view, 5, D=D))
+    assert rep["R"] > 300_000
+
+
+def test_config5_three_million_surfels(hip_lib, oracle_mod, capsys):
+    """BASELINE config 5 stand-in (S5): 3 M surfels, SH degree 3, all seven `allmap` cotangents non-zero (what the
+    depth / normal / distortion regularisers of train_with_refine_depth.py:391-396 produce)."""
+    inp = room_inputs(3_000_000, 1200, 680, 0, 8)
+    rep, h, o = full_size_case(oracle_mod, capsys, "S5 view 0", inp)
+    assert rep["R"] > 6_000_000  # (cotangents(): N(0,1) on all three colour and all seven allmap planes)
 
 
 @pytest.mark.parametrize("backward", ["policy", "one-wave"])
@@ -371,14 +355,9 @@ def test_fuzz_small_scenes(hip_lib, oracle_mod, block, backward, monkeypatch):
         o = run_oracle(oracle_mod, inp, g)
         h = run_hip(inp, g)
         tag = f"seed {seed}: P={P} {W}x{H} D={D}"
-        assert h["R"] == o["R"], tag
-        np.testing.assert_array_equal(h["radii"], o["radii"], err_msg=tag)
-        assert np.abs(h["color"] - o["color"]).max() <= OUT_ATOL, tag
-        assert np.abs(h["others"] - o["others"]).max() <= OUT_ATOL, tag
+        assert_parity(h, o, inp, oracle_mod, tag=tag)
         if o["R"] > 0:
             check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
-        for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
-            assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, (tag, name)
 
 
 @pytest.mark.parametrize("switch", ["G4S_BOX_ONLY", "G4S_NO_FASTPATH", "G4S_BWD_FWD_ORDER"])
@@ -445,8 +424,7 @@ def test_hot_tiles(hip_lib, oracle_mod):
     st = hip_state(h, inp)
     n = st["ranges"][:, 1] - st["ranges"][:, 0]
     assert n.max() > 5000
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 def test_deep_tile_backward_matches_the_one_wave_backward(hip_lib, oracle_mod):
@@ -485,7 +463,7 @@ def test_deep_tile_backward_matches_the_one_wave_backward(hip_lib, oracle_mod):
                     assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-30), (seed, thr, k)
         if seed < 6:
             o = run_oracle(oracle_mod, inp, g)
-            check_grads(grads_with(inp, g, 0), o)
+            assert_parity(grads_with(inp, g, 0), o, inp, oracle_mod, tag=f"seed {seed}")
     # metric size: all 7 500 tiles through the four-wave kernel
     P, W, H = 1_500_000, 1600, 1200
     scene = synthetic.scene_room(P, seed=0)
@@ -535,8 +513,7 @@ def test_outlier_tiles_in_a_full_frame(hip_lib, oracle_mod):
         differs = differs or not np.array_equal(a, b)
     assert differs  # i.e. the four-wave kernel really ran (its sums are associated differently)
     o = run_oracle(oracle_mod, inp, g)
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 def test_hair_thin_splat_found_by_the_fuzz_sweep(hip_lib, oracle_mod):
@@ -558,8 +535,7 @@ def test_hair_thin_splat_found_by_the_fuzz_sweep(hip_lib, oracle_mod):
     g = cotangents(H, W, seed=seed)
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
-    check_forward(h, o)
-    check_grads(h, o)
+    assert_parity(h, o, inp, oracle_mod)
 
 
 def test_largest_tile_grid(hip_lib, oracle_mod):
@@ -571,16 +547,9 @@ def test_largest_tile_grid(hip_lib, oracle_mod):
     g = cotangents(4096, 4096, seed=6)
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
-    # ~10^9 (pixel, splat) evaluations: the statistical bar of test_metric_size_vs_oracle (rare threshold flips)
-    assert h["R"] == o["R"]
-    np.testing.assert_array_equal(h["radii"], o["radii"])
-    N = 4096 * 4096
-    bad = (np.abs(h["color"] - o["color"]).max(axis=0) > OUT_ATOL) | (np.abs(h["others"] - o["others"]).max(axis=0) > OUT_ATOL)
-    assert bad.sum() <= 2e-5 * N, int(bad.sum())
+    # ~10^9 (pixel, splat) evaluations: the same proof as at the metric's size
+    assert_parity(h, o, inp, oracle_mod, tag="4096x4096")
     assert np.median(np.abs(h["color"] - o["color"])) <= 1e-6
-    for name in ("means3D", "scales", "rotations", "opacity", "sh", "transMat", "means2D"):
-        a, b = h["grads"][name].astype(np.float64), o["grads"][name].astype(np.float64)
-        assert np.linalg.norm(a - b) <= GRAD_RTOL * np.linalg.norm(b), name
     big = dict(inp)
     big["W"] = 4097
     with pytest.raises(RuntimeError, match="tiles"):

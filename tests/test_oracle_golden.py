@@ -147,3 +147,27 @@ def test_remaining_losses_match_the_reference():
     assert abs(float(metrics.l2_loss(a, b)) - float(d["l2"])) <= 1e-7
     assert abs(float(metrics.smooth_loss(disp, a)) - float(d["smooth"])) <= 1e-6
     np.testing.assert_allclose(metrics.mse(a, b).numpy(), d["mse"], rtol=1e-6)
+
+
+def test_render_maps_ref_matches_the_reference_render_tail():
+    """oracle/render_maps_ref.py against the reference's own render() tail + point_utils, values and autograd
+    gradients (fixture made by tests/golden/make_golden_maps.py by running the reference's code on the CPU)."""
+    from types import SimpleNamespace
+    import torch
+    from oracle.render_maps_ref import render_maps
+    z = np.load(os.path.join(G, "render_tail.npz"))
+    names = ("rend_alpha", "rend_normal", "rend_normal_cam", "rend_depth", "rend_dist", "surf_depth", "surf_normal", "surf_normal_cam")
+    for ci in range(3):
+        W, H, ratio = z[f"c{ci}_meta"]
+        cam = SimpleNamespace(image_width=int(W), image_height=int(H), world_view_transform=torch.tensor(z[f"c{ci}_wvt"]),
+                              full_proj_transform=torch.tensor(z[f"c{ci}_fpt"]))
+        am = torch.tensor(z[f"c{ci}_allmap"], requires_grad=True)
+        out = render_maps(am, cam, float(ratio))
+        for m in names:
+            np.testing.assert_allclose(out[m].detach().numpy(), z[f"c{ci}_{m}"], rtol=0, atol=1e-6, err_msg=m)
+        sum((out[m] * torch.tensor(z[f"c{ci}_cot_{m}"])).sum() for m in names).backward()
+        want = z[f"c{ci}_dL_dallmap"]
+        got = am.grad.numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.isnan(want).any()  # alpha == 0 pixels: torch's 0/0 backward, part of the reference's behaviour
+        np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), rtol=1e-5, atol=1e-6 * np.nanmax(np.abs(want)))
