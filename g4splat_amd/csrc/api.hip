@@ -437,13 +437,8 @@ static int rasterizer_backward_impl(
     if (radii == nullptr) radii = (const int*)(geom + GL.internal_radii);
     float* grad_inst = (float*)align_ptr(workspace);
 
-    // dL_dsh is mostly zero rows (invisible Gaussians): fill it once at memset speed, K8 only writes
-    // the visible rows.  Issued ahead of the (VALU-bound) blend backward.
-    if (M > 0 && shs_rest == nullptr) HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * M * 3 * sizeof(float), stream));
-    if (M > 0 && shs_rest != nullptr) {
-        HIP_TRY(hipMemsetAsync(dL_dsh, 0, (size_t)P * 3 * sizeof(float), stream));
-        if (M > 1) HIP_TRY(hipMemsetAsync(dL_dsh_rest, 0, (size_t)P * (M - 1) * 3 * sizeof(float), stream));
-    }
+    // (dL_dsh is mostly zero rows -- invisible Gaussians; K8's fold kernel clears exactly those rows while it waits for
+    // its gather, K8b writes the others: no memset of the 192 B x P tensor)
     // gradient records: only instances that receive a contribution are written by the blend backward; instead of
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
     float* gsum = (float*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));

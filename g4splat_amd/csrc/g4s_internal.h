@@ -24,24 +24,16 @@ constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 1
 //        (centre e, unit major axis u, semi-axes a >= b) that the alpha-cutoff disk of the splat projects to and of
 //        the low-pass disk |pixel - centre|^2 <= r2 -- slightly enlarged; valid = 0: no ellipse, use the box
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
-constexpr int SORT_CHUNK_MAX = 2048;  // keys per wave-private radix chunk (upper bound)
-// Chunk length for n keys: one wave per chunk; aim for ~8 waves per CU so that the per-wave serial
-// chain (chunk/64 steps) is short and the chip is full, within [256, 2048], a multiple of 64.
-__host__ __device__ inline int sort_chunk(size_t n) {
-    size_t c = (n + 2047) / 2048;  // 256 CUs x 8 waves
-    c = (c + 63) / 64 * 64;
-    if (c < 256) c = 256;
-    if (c > (size_t)SORT_CHUNK_MAX) c = SORT_CHUNK_MAX;
-    return (int)c;
-}
-__host__ __device__ inline int sort_nchunks(size_t n) { return (int)((n + sort_chunk(n) - 1) / sort_chunk(n)); }
-// upper bound of sort_nchunks(n) over all n <= n_max (grid size when n only lives on the device)
-inline int sort_nchunks_max(size_t n_max) {
-    const size_t fine = (n_max + 255) / 256 + 1;             // chunks of 256 (small n)
-    const size_t coarse = (n_max + SORT_CHUNK_MAX - 1) / SORT_CHUNK_MAX + 1;  // chunks of 2048 (n > 4.2 M: the count grows again)
-    const size_t mid = fine < 2112 ? fine : 2112;            // in between the chunk length grows with n: <= 2048 + rounding
-    return (int)(mid > coarse ? mid : coarse);
-}
+// Keys per thread of the radix passes (a workgroup of 256 threads owns 256 * ITEMS consecutive keys).
+#ifndef G4S_SORT_ITEMS_U32
+#define G4S_SORT_ITEMS_U32 8
+#endif
+#ifndef G4S_SORT_ITEMS_U64
+#define G4S_SORT_ITEMS_U64 16
+#endif
+constexpr int SORT_ITEMS_U32 = G4S_SORT_ITEMS_U32;  // depth sort of the emitting Gaussians (32-bit keys + index)
+constexpr int SORT_ITEMS_U64 = G4S_SORT_ITEMS_U64;  // tile partition of the packed instances
+inline size_t sort_blocks(size_t n, int items) { return (n + (size_t)256 * items - 1) / ((size_t)256 * items); }
 // Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
 // <= 65536), 31..0 Gaussian index.  Every field sits on a natural 16/32-bit boundary on purpose:
 // hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load and then drops the mask.
@@ -58,12 +50,10 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 struct GeomLayout {
     size_t rec, clamped, tiles_touched, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
         block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, vis_block_sums, vis_block_offs, total, bytes;
-    int nchunks;   // radix chunks over P
     int nblocks;   // 256-wide blocks over P
 };
 struct BinLayout {
     size_t ent_a, ent_b, hist, bin_total, qhit, bytes;
-    int nchunks;
 };
 struct ImgLayout {
     size_t ranges, final_T, n_contrib, tile_order, tile_depth, tile_order_bwd, bytes;
@@ -73,7 +63,6 @@ inline GeomLayout geom_layout(size_t P) {
     GeomLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
-    L.nchunks = sort_nchunks(P);
     L.nblocks = (int)((P + 255) / 256);
     L.rec = take(P * REC_FLOATS * 4);
     L.clamped = take(P);
@@ -83,8 +72,8 @@ inline GeomLayout geom_layout(size_t P) {
     L.keys_b = take(P * 4);
     L.vals_a = take(P * 4);
     L.vals_b = take(P * 4);
-    // the depth sort runs over the emitting Gaussians only (n <= P): capacity for the finest chunking of any n <= P
-    L.hist = take((size_t)256 * (size_t)sort_nchunks_max(P) * 4);
+    // the depth sort runs over the emitting Gaussians only (n <= P): capacity for n = P
+    L.hist = take((size_t)256 * (sort_blocks(P, SORT_ITEMS_U32) + 1) * 4);
     L.bin_total = take(256 * 4);
     L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
@@ -101,10 +90,9 @@ inline BinLayout bin_layout(size_t R) {
     BinLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
-    L.nchunks = (int)((R + 255) / 256);  // capacity for the finest chunking of any n <= R
     L.ent_a = take((R ? R : 1) * 8);
     L.ent_b = take((R ? R : 1) * 8);
-    L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
+    L.hist = take((size_t)256 * (sort_blocks(R, SORT_ITEMS_U64) + 1) * 4);
     L.bin_total = take(256 * 4);
     L.qhit = take((R ? R : 1));
     L.bytes = o + 256;

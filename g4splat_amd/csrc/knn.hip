@@ -20,17 +20,16 @@ constexpr int BOX = 1024;
 
 struct KnnLayout {
     size_t keys_a, keys_b, vals_a, vals_b, hist, bin_total, sorted, boxes, partial, bbox, bytes;
-    int nchunks, nboxes, nparts;
+    int nboxes, nparts;
 };
 static KnnLayout knn_layout(size_t P) {
     KnnLayout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o = align_up(o + n); return r; };
-    L.nchunks = sort_nchunks(P);
     L.nboxes = (int)((P + BOX - 1) / BOX);
     L.nparts = (int)((P + 1023) / 1024);
     L.keys_a = take(P * 4); L.keys_b = take(P * 4); L.vals_a = take(P * 4); L.vals_b = take(P * 4);
-    L.hist = take((size_t)256 * (L.nchunks ? L.nchunks : 1) * 4);
+    L.hist = take((size_t)256 * (sort_blocks(P, SORT_ITEMS_U32) + 1) * 4);
     L.bin_total = take(256 * 4);
     L.sorted = take(P * 16);
     L.boxes = take((size_t)(L.nboxes ? L.nboxes : 1) * 32);

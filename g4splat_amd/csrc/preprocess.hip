@@ -586,159 +586,208 @@ constexpr int K8_SUM_STRIDE = GRAD_FLOATS + 1;  // LDS row stride, odd => confli
 
 // K8a: fold only (few registers => full occupancy for a latency-bound gather); the per-Gaussian
 // sums go to gsum[P][18] with coalesced stores.
-__global__ void __launch_bounds__(256) fold_records_kernel(PreprocessBwdArgs a) {
-    __shared__ float s_sum[256 * K8_SUM_STRIDE];
-    __shared__ uint32_t s_off[256], s_cnt[256];
+//
+// A ROW of 16 lanes folds one Gaussian, four Gaussians per wave at a time, two such groups in flight: lane (kk, c)
+// of a row reads quad c of record 4 s + kk, s = 0, 1, ... -- a typical run of ~10 records is three steps, all
+// of whose loads are issued before any is consumed -- and the four kk partials are combined with two DPP row
+// rotates.  The first design spent a whole wave (and two ds_bpermute exchanges) on every Gaussian: ~100 wave
+// instructions per visible Gaussian, 40 M per launch at S3 -- it was bound by instruction issue, not by memory
+// (0.169 ms for 0.44 GB).  Summation order: fixed (per lane ascending record index, then the DPP tree), so the
+// gradients stay bit-reproducible.
+//
+// The kernel also clears the dL_dsh rows of the Gaussians preprocess_bwd will not write (radii == 0) -- 72 % of a
+// 288 MB tensor at S3 -- with coalesced stores that overlap its own latency-bound gather; that used to be a separate
+// 0.038 ms memset.
+struct FoldShZero {
+    float* base;      // dL_dsh (or its [P,M-1,3] rest part); NULL = nothing to clear
+    int row_floats;   // floats per Gaussian
+};
+__device__ __forceinline__ void fold_zero_rows(const FoldShZero z, int P, const uint8_t* s_vis) {
+    if (z.base == nullptr) return;
+    const int t = (int)threadIdx.x;
+    const int rows = imin_(256, P - (int)blockIdx.x * 256);
+    const size_t first = (size_t)blockIdx.x * 256 * z.row_floats;
+    const int total = rows * z.row_floats;
+    float* dst = z.base + first;
+    if ((z.row_floats & 3) == 0 && (((size_t)dst) & 15) == 0) {  // rows are whole 16-byte quads
+        const int rq = z.row_floats >> 2;
+        for (int q = t; q < (total >> 2); q += 256)
+            if (!s_vis[q / rq]) reinterpret_cast<float4*>(dst)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int i = t; i < total; i += 256)
+            if (!s_vis[i / z.row_floats]) dst[i] = 0.0f;
+    }
+}
+
+// Phase 1 of K8 (device function: all 256 threads of the block call it).  On return -- after the trailing barrier --
+// s_sum[g * K8_SUM_STRIDE + i] holds folded term i of local Gaussian g.
+__device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const FoldShZero z0, const FoldShZero z1,
+                                           float* s_sum, uint32_t* s_off, uint32_t* s_cnt, uint8_t* s_vis) {
     const int t = (int)threadIdx.x;
     const int idx = (int)(blockIdx.x * 256 + t);
     const bool in_range = idx < a.P;
     const bool visible = in_range && a.radii[idx] > 0;
     const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)(in_range ? idx : 0) * REC_QUADS;
-    {
-        uint32_t off = 0, cnt = 0;
-        if (visible) {
-            const float4 q0 = rq[0];
-            off = __float_as_uint(q0.z);
-            cnt = __float_as_uint(q0.w) & ~REC_NO_LOWPASS;
-        }
-        s_off[t] = off;
-        s_cnt[t] = cnt;
+    uint32_t my_off = 0, my_cnt = 0;
+    if (visible) {
+        const float4 q0 = rq[0];
+        my_off = __float_as_uint(q0.z);
+        my_cnt = __float_as_uint(q0.w) & ~REC_NO_LOWPASS;
     }
+    s_off[t] = my_off;
+    s_cnt[t] = my_cnt;
+    s_vis[t] = visible ? 1 : 0;
     __syncthreads();
-    // Fold, wave-cooperative: every wave walks its own 64 Gaussians' visible members (ballot +
-    // scalar bit scan), four at a time.  For one Gaussian the 64 lanes read 16 records x 4 quads
-    // (terms 0..15) per step -- one coalesced 16-byte load per lane covers a whole typical run --
-    // and a float2 per record for terms 16..17; the partial sums are combined with DPP row rotates
-    // and two cross-row exchanges in a fixed order.  A Gaussian with hundreds of instances costs
-    // cnt/16 steps of one wave instead of serialising a single thread.
+    fold_zero_rows(z0, a.P, s_vis);
+    fold_zero_rows(z1, a.P, s_vis);
     {
         const int lane = lane_id();
         const int wbase = (t >> 6) * 64;  // first local Gaussian of this wave
-        const uint32_t my_cnt = s_cnt[t], my_off = s_off[t];
-        uint64_t vis = __ballot(my_cnt != 0);
-        const int kk = lane >> 2, c = lane & 3;
-        constexpr int U = 8;  // Gaussians in flight per iteration
+        const int row = lane >> 4, kk = (lane >> 2) & 3, c = lane & 3;
+        // Runs longer than FOLD_ROW_MAX records (near splats that cover hundreds of tiles) are folded by the whole
+        // wave, 128 records per trip; in a 16-lane row they would take cnt/16 dependent round trips while the rest of
+        // the wave idles (one 2 000-instance splat: 125 trips)
+        constexpr uint32_t FOLD_ROW_MAX = 48;
+        uint64_t big = __ballot(my_cnt > FOLD_ROW_MAX);
+        while (big) {
+            const int j = (int)__builtin_ctzll(big);
+            big &= big - 1;
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, j);
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)my_off, j);
+            const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)off * GRAD_STRIDE);
+            const uint32_t k16 = (uint32_t)(lane >> 2);  // record within a group of 16
+            float4 sA = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 sB = make_float2(0.f, 0.f);
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 128) {
+                float4 x[8];
+                uint8_t f[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t k = k0 + 16 * i + k16;
+                    const uint32_t kc = k < cnt ? k : 0u;
+                    x[i] = base4[(size_t)kc * (GRAD_STRIDE / 4) + c];
+                    f[i] = a.rec_flag[off + kc];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t k = k0 + 16 * i + k16;
+                    if (k < cnt && (f[i] & 1)) { sA.x += x[i].x; sA.y += x[i].y; sA.z += x[i].z; sA.w += x[i].w; }
+                    if (k < cnt && (f[i] & 2) && c == 0) {
+                        const float2 y = *reinterpret_cast<const float2*>(a.grad_inst + (size_t)(off + k) * GRAD_STRIDE + 16);
+                        sB.x += y.x; sB.y += y.y;
+                    }
+                }
+            }
+            // over the 16 record lanes: two rotates inside each row of 16, then the four rows
+            sA.x += dpp_f32<0x124>(sA.x); sA.y += dpp_f32<0x124>(sA.y); sA.z += dpp_f32<0x124>(sA.z); sA.w += dpp_f32<0x124>(sA.w);
+            sA.x += dpp_f32<0x128>(sA.x); sA.y += dpp_f32<0x128>(sA.y); sA.z += dpp_f32<0x128>(sA.z); sA.w += dpp_f32<0x128>(sA.w);
+            sA.x += __shfl_xor(sA.x, 16, 64); sA.y += __shfl_xor(sA.y, 16, 64); sA.z += __shfl_xor(sA.z, 16, 64); sA.w += __shfl_xor(sA.w, 16, 64);
+            sA.x += __shfl_xor(sA.x, 32, 64); sA.y += __shfl_xor(sA.y, 32, 64); sA.z += __shfl_xor(sA.z, 32, 64); sA.w += __shfl_xor(sA.w, 32, 64);
+            sB.x += dpp_f32<0x124>(sB.x); sB.y += dpp_f32<0x124>(sB.y);
+            sB.x += dpp_f32<0x128>(sB.x); sB.y += dpp_f32<0x128>(sB.y);
+            sB.x += __shfl_xor(sB.x, 16, 64); sB.y += __shfl_xor(sB.y, 16, 64);
+            sB.x += __shfl_xor(sB.x, 32, 64); sB.y += __shfl_xor(sB.y, 32, 64);
+            float* dst = s_sum + (wbase + j) * K8_SUM_STRIDE;
+            if (lane < 4) { dst[4 * lane] = sA.x; dst[4 * lane + 1] = sA.y; dst[4 * lane + 2] = sA.z; dst[4 * lane + 3] = sA.w; }
+            if (lane == 0) { dst[16] = sB.x; dst[17] = sB.y; }
+        }
+        uint64_t vis = __ballot(my_cnt != 0 && my_cnt <= FOLD_ROW_MAX);
+        constexpr int U = 2;  // groups of four Gaussians in flight
         while (vis) {
+            // group u, row r folds the (4 u + r)-th remaining member of the wave that has records
             int jj[U];
             uint32_t cn[U], of[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                jj[u] = vis ? (int)__builtin_ctzll(vis) : -1;
-                if (vis) vis &= vis - 1;
-                cn[u] = jj[u] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, jj[u] < 0 ? 0 : jj[u]) : 0u;
-                of[u] = jj[u] >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)my_off, jj[u] < 0 ? 0 : jj[u]) : 0u;
+                uint64_t m = vis;
+                for (int i = 0; i < row; i++) m &= m - 1;  // drop the members the lower rows take
+                jj[u] = m ? (int)__builtin_ctzll(m) : -1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) vis &= vis - 1;  // (scalar) the four members of this group are taken
+                cn[u] = jj[u] >= 0 ? s_cnt[wbase + jj[u]] : 0u;
+                of[u] = jj[u] >= 0 ? s_off[wbase + jj[u]] : 0u;
             }
-            // common case first, with every load of the iteration issued before any is consumed:
-            // records 0..15 (terms 0..15, 16 records x 4 quads) and records 0..63 (terms 16..17)
-            float4 accA[U];
+            float4 acc[U];
             float2 accB[U];
-            uint8_t fA[U], fB[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
-                const float2* base2 = reinterpret_cast<const float2*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
-                accA[u] = base4[(size_t)((uint32_t)kk < cn[u] ? kk : 0) * (GRAD_STRIDE / 4) + c];
-                accB[u] = base2[(size_t)((uint32_t)lane < cn[u] ? lane : 0) * (GRAD_STRIDE / 2) + 8];
-                fA[u] = a.rec_flag[of[u] + ((uint32_t)kk < cn[u] ? kk : 0)];
-                fB[u] = a.rec_flag[of[u] + ((uint32_t)lane < cn[u] ? lane : 0)];
-            }
-            // records the blend backward never wrote hold garbage (possibly NaN): select, do not multiply
+            for (int u = 0; u < U; u++) { acc[u] = make_float4(0.f, 0.f, 0.f, 0.f); accB[u] = make_float2(0.f, 0.f); }
+            // the longest run of the eight decides the trip count (uniform); four steps = 16 records per trip
+            uint32_t cmax = 0;  // scalar: cn[u] is uniform inside a row
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const bool ma = (uint32_t)kk < cn[u] && (fA[u] & 1), mb = (uint32_t)lane < cn[u] && (fB[u] & 2);
-                accA[u].x = ma ? accA[u].x : 0.0f; accA[u].y = ma ? accA[u].y : 0.0f;
-                accA[u].z = ma ? accA[u].z : 0.0f; accA[u].w = ma ? accA[u].w : 0.0f;
-                accB[u].x = mb ? accB[u].x : 0.0f; accB[u].y = mb ? accB[u].y : 0.0f;
-            }
-            // long runs (rare): the remaining records, in ascending order
+            for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (cn[u] <= 16) continue;  // uniform
-                const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
-                const float2* base2 = reinterpret_cast<const float2*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
-                // 128 records per trip: eight independent 16-byte loads + two 8-byte loads in flight per
-                // lane, so a Gaussian with thousands of instances is not a serial chain of round trips
-                for (uint32_t k0 = 16; k0 < cn[u]; k0 += 128) {
-                    float4 x[8];
-                    uint8_t f[8];
+                for (int r = 0; r < 4; r++) cmax = max(cmax, (uint32_t)__builtin_amdgcn_readlane((int)cn[u], 16 * r));
+            for (uint32_t k0 = 0; k0 < cmax; k0 += 16) {
+                float4 x[U][4];
+                uint8_t f[U][4];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const uint32_t k = k0 + 16 * i + kk;
-                        x[i] = base4[(size_t)(k < cn[u] ? k : 0) * (GRAD_STRIDE / 4) + c];
-                        f[i] = a.rec_flag[of[u] + (k < cn[u] ? k : 0)];
+                for (int u = 0; u < U; u++) {
+                    const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t k = k0 + 4 * i + kk;
+                        const uint32_t kc = k < cn[u] ? k : 0u;
+                        x[u][i] = base4[(size_t)kc * (GRAD_STRIDE / 4) + c];
+                        f[u][i] = a.rec_flag[of[u] + kc];
                     }
+                }
+                // records the blend backward never wrote hold garbage (possibly NaN): select, do not multiply
 #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        if ((k0 + 16 * i + kk) < cn[u] && (f[i] & 1)) {
-                            accA[u].x += x[i].x; accA[u].y += x[i].y; accA[u].z += x[i].z; accA[u].w += x[i].w;
+                for (int u = 0; u < U; u++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t k = k0 + 4 * i + kk;
+                        const bool ok = k < cn[u];
+                        if (ok && (f[u][i] & 1)) {
+                            acc[u].x += x[u][i].x; acc[u].y += x[u][i].y; acc[u].z += x[u][i].z; acc[u].w += x[u][i].w;
+                        }
+                        if (ok && (f[u][i] & 2) && c == 0) {  // the rare low-pass centre terms 16..17
+                            const float2 y = *reinterpret_cast<const float2*>(a.grad_inst + (size_t)(of[u] + k) * GRAD_STRIDE + 16);
+                            accB[u].x += y.x; accB[u].y += y.y;
                         }
                     }
                 }
-                for (uint32_t k0 = 64; k0 < cn[u]; k0 += 256) {
-                    float2 y[4];
-                    uint8_t f[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t kb = k0 + 64 * i + lane;
-                        y[i] = base2[(size_t)(kb < cn[u] ? kb : 0) * (GRAD_STRIDE / 2) + 8];
-                        f[i] = a.rec_flag[of[u] + (kb < cn[u] ? kb : 0)];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if ((k0 + 64 * i + lane) < cn[u] && (f[i] & 2)) { accB[u].x += y[i].x; accB[u].y += y[i].y; }
-                    }
-                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (jj[u] < 0) continue;  // uniform
-                float4 sA = accA[u];
+                float4 sA = acc[u];
                 float2 sB = accB[u];
-                // over kk = lane >> 2 (16 values): rotate by 4 and 8 lanes inside each row of 16, then rows
+                // over kk: rotate by 4 and 8 lanes inside the row of 16
                 sA.x += dpp_f32<0x124>(sA.x); sA.y += dpp_f32<0x124>(sA.y); sA.z += dpp_f32<0x124>(sA.z); sA.w += dpp_f32<0x124>(sA.w);
                 sA.x += dpp_f32<0x128>(sA.x); sA.y += dpp_f32<0x128>(sA.y); sA.z += dpp_f32<0x128>(sA.z); sA.w += dpp_f32<0x128>(sA.w);
-                sA.x += __shfl_xor(sA.x, 16, 64); sA.y += __shfl_xor(sA.y, 16, 64); sA.z += __shfl_xor(sA.z, 16, 64); sA.w += __shfl_xor(sA.w, 16, 64);
-                sA.x += __shfl_xor(sA.x, 32, 64); sA.y += __shfl_xor(sA.y, 32, 64); sA.z += __shfl_xor(sA.z, 32, 64); sA.w += __shfl_xor(sA.w, 32, 64);
-                sB.x = wave_sum_to_lane63(sB.x);
-                sB.y = wave_sum_to_lane63(sB.y);
-                float* dst = s_sum + (wbase + jj[u]) * K8_SUM_STRIDE;
-                if (lane < 4) {  // kk == 0, c = lane: terms 4c..4c+3
-                    dst[4 * lane] = sA.x; dst[4 * lane + 1] = sA.y; dst[4 * lane + 2] = sA.z; dst[4 * lane + 3] = sA.w;
+                sB.x += dpp_f32<0x124>(sB.x); sB.y += dpp_f32<0x124>(sB.y);
+                sB.x += dpp_f32<0x128>(sB.x); sB.y += dpp_f32<0x128>(sB.y);
+                if (jj[u] >= 0 && kk == 0) {
+                    float* dst = s_sum + (wbase + jj[u]) * K8_SUM_STRIDE;
+                    dst[4 * c] = sA.x; dst[4 * c + 1] = sA.y; dst[4 * c + 2] = sA.z; dst[4 * c + 3] = sA.w;  // terms 4c..4c+3
+                    if (c == 0) { dst[16] = sB.x; dst[17] = sB.y; }
                 }
-                if (lane == 63) { dst[16] = sB.x; dst[17] = sB.y; }
             }
         }
-        // invisible members fold to zero
+        // members without records fold to zero
         if (my_cnt == 0) {
 #pragma unroll
             for (int i = 0; i < GRAD_FLOATS; i++) s_sum[t * K8_SUM_STRIDE + i] = 0.0f;
         }
     }
     __syncthreads();
-    // coalesced write-out of the block's 256 x 18 sums
-    {
-        const size_t gbase = (size_t)blockIdx.x * 256 * GRAD_FLOATS;
-        const int nvalid = imin_(256, a.P - (int)blockIdx.x * 256) * GRAD_FLOATS;
-        for (int i = t; i < nvalid; i += 256) a.gsum[gbase + i] = s_sum[(i / GRAD_FLOATS) * K8_SUM_STRIDE + (i % GRAD_FLOATS)];
-    }
 }
 
-// K8b: one thread per Gaussian; the folded terms arrive through LDS (coalesced load of the block's
-// 256 x 18 floats).
+// K8: fold (phase 1, above) + one thread per Gaussian (phase 2) in ONE kernel: the 256 x 18 folded terms of the
+// block stay in LDS -- the first design wrote them to HBM from a lean fold kernel and read them back here
+// (2 x 108 MB at S3 and a launch), to give the gather more resident waves; once the fold stopped being issue-bound
+// (16-lane rows) that round trip was the larger cost.
 template <int SH_MODE>
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a, FoldShZero z0, FoldShZero z1) {
     __shared__ float s_sum[256 * K8_SUM_STRIDE];
+    __shared__ uint32_t s_off[256], s_cnt[256];
+    __shared__ uint8_t s_vis[256];
     const int t = (int)threadIdx.x;
     const int idx = (int)(blockIdx.x * 256 + t);
     const bool in_range = idx < a.P;
-    const bool visible = in_range && a.radii[idx] > 0;
+    fold_block(a, z0, z1, s_sum, s_off, s_cnt, s_vis);
+    const bool visible = s_vis[t] != 0;
     const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)(in_range ? idx : 0) * REC_QUADS;
-    {
-        const size_t gbase = (size_t)blockIdx.x * 256 * GRAD_FLOATS;
-        const int nvalid = imin_(256, a.P - (int)blockIdx.x * 256) * GRAD_FLOATS;
-        for (int i = t; i < nvalid; i += 256) s_sum[(i / GRAD_FLOATS) * K8_SUM_STRIDE + (i % GRAD_FLOATS)] = a.gsum[gbase + i];
-    }
-    __syncthreads();
     if (!in_range) return;
 
     // record order (blend backward): 0..14 = colour, normal, T; 15 = opacity; 16..17 = low-pass centre terms
@@ -867,8 +916,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         dmean2[0] = (float)(dT_out[2] * depth_T8 * 0.5 * (float)a.W);
         dmean2[1] = (float)(dT_out[5] * depth_T8 * 0.5 * (float)a.H);
     }
-    // rows of dL_dsh that belong to invisible Gaussians were zero-filled by the caller (one
-    // hipMemsetAsync at copy-engine speed instead of 192-byte strided stores from here)
+    // rows of dL_dsh that belong to invisible Gaussians were cleared by fold_records_kernel (coalesced, block-wide)
 
     a.dL_dmean2D[3 * idx] = dmean2[0]; a.dL_dmean2D[3 * idx + 1] = dmean2[1]; a.dL_dmean2D[3 * idx + 2] = dmean2[2];
     if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5]; }
@@ -883,11 +931,20 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(fold_records_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    // dL_dsh rows of the Gaussians phase 2 does not write are cleared by the fold phase (no separate memset)
+    FoldShZero z0{nullptr, 0}, z1{nullptr, 0};
+    if (a.M > 0 && a.dL_dsh != nullptr) {
+        if (a.shs_rest != nullptr) {
+            z0 = FoldShZero{a.dL_dsh, 3};
+            if (a.M > 1) z1 = FoldShZero{a.dL_dsh_rest, (a.M - 1) * 3};
+        } else {
+            z0 = FoldShZero{a.dL_dsh, a.M * 3};
+        }
+    }
     const dim3 grid((a.P + 255) / 256), block(256);
-    if (a.shs_rest != nullptr) hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, 0, s, a);
-    else if (a.sh_vec16) hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, 0, s, a);
+    if (a.shs_rest != nullptr) hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, 0, s, a, z0, z1);
+    else if (a.sh_vec16) hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, 0, s, a, z0, z1);
+    else hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, 0, s, a, z0, z1);
 }
 
 }  // namespace g4s

@@ -4,7 +4,7 @@
 # Every other translation unit is taken from the objects of the regular build (run make first).
 set -eu
 CS=$(dirname "$0")/../g4splat_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function -I$CS"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function -I$CS ${EXTRA:-}"
 out="${@: -1}"
 objs=""
 declare -A repl
