@@ -13,7 +13,8 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB_PATH)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
-    srcs.append(os.path.join(_HERE, "..", "include", "g4s_rasterizer.h"))
+    inc = os.path.join(_HERE, "..", "include")
+    srcs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]  # every public header is a Makefile dependency
     return any(os.path.getmtime(s) > t for s in srcs)
 
 

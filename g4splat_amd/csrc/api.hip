@@ -31,11 +31,12 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-// One pinned word per host thread for the num_rendered read-back.
+// One pinned word per host thread for the num_rendered read-back.  hipHostMallocPortable: the same host thread may
+// drive several devices (one process, eight GPUs), and only a portable allocation is pinned for all of them.
 uint32_t* pinned_word() {
     thread_local uint32_t* p = nullptr;
     if (!p) {
-        if (hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) p = nullptr;
+        if (hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) p = nullptr;
     }
     return p;
 }

@@ -38,7 +38,13 @@ class GaussianRasterizationSettings(NamedTuple):
 
 def _snapshot(args):
     """Host copy of an argument tuple, taken before a debug-mode launch can corrupt it (:17-19)."""
-    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+    def host(a):
+        if isinstance(a, torch.Tensor):
+            return a.detach().cpu().clone()
+        if isinstance(a, (tuple, list)):  # the split-SH pair (features_dc, features_rest)
+            return tuple(host(x) for x in a)
+        return a
+    return tuple(host(a) for a in args)
 
 
 def _call_guarded(fn, args, debug, dump_name, banner):
@@ -111,7 +117,9 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         fwd_args = (rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
                     (sh_dc, sh_rest), rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*fwd_args)
+        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
+            _C.rasterize_gaussians, fwd_args, rs.debug, "snapshot_fw.dump",
+            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, radii, sh_dc, sh_rest, geomBuffer,
@@ -126,11 +134,13 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
          imgBuffer) = ctx.saved_tensors
         grad_out_color, grad_depth = _present(grad_out_color, grad_depth, rs, means3D.device)
         empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        bwd_args = (rs.bg, means3D, radii, empty, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                    rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, (sh_dc, sh_rest), rs.sh_degree,
+                    rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, _grad_colors, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = _C.rasterize_gaussians_backward(
-            rs.bg, means3D, radii, empty, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
-            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, (sh_dc, sh_rest), rs.sh_degree,
-            rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
+         grad_rotations) = _call_guarded(
+            _C.rasterize_gaussians_backward, bwd_args, rs.debug, "snapshot_bw.dump",
+            "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         return (grad_means3D, grad_means2D, grad_sh[0], grad_sh[1], grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
 

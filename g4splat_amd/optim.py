@@ -14,10 +14,26 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *, foreach=None,
+                 maximize=False, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
             raise ValueError("invalid Adam hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # torch.optim.Adam's full set of param-group keys, so that state_dict()s move between the two classes in both
+        # directions (GaussianModel.capture() / restore(), and the reference's own restore()); the kernel implements
+        # the plain update only, so anything but the defaults is refused -- here and again in step(), because
+        # load_state_dict() overwrites the groups.
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize,
+                        foreach=foreach, capturable=capturable, differentiable=differentiable, fused=fused,
+                        decoupled_weight_decay=decoupled_weight_decay)
+        self._check_plain(defaults)
+        super().__init__(params, defaults)
+
+    @staticmethod
+    def _check_plain(group):
+        if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False) or \
+                group.get("capturable", False) or group.get("differentiable", False) or group.get("decoupled_weight_decay", False):
+            raise ValueError("FusedAdam implements plain Adam only: weight_decay, amsgrad, maximize, capturable, "
+                             "differentiable and decoupled_weight_decay must keep their defaults")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -29,6 +45,7 @@ class FusedAdam(torch.optim.Optimizer):
         # (betas, eps, device) -> segments; the reference uses one setting for all groups => one launch per 8 tensors
         batches = {}
         for group in self.param_groups:
+            self._check_plain(group)
             for p in group["params"]:
                 if p.grad is None:
                     continue

@@ -69,3 +69,61 @@ def test_dropin_module_names():
     from diff_surfel_rasterization import GaussianRasterizationSettings as S2
     assert d.GaussianRasterizer is GaussianRasterizer and S2 is GaussianRasterizationSettings
     assert callable(distCUDA2) and callable(d._C.rasterize_gaussians) and callable(d._C.mark_visible)
+
+
+def test_fused_adam_state_dict_is_interchangeable_with_torch_adam():
+    """a checkpoint captured with FusedAdam must load into torch.optim.Adam (the reference's restore()) and
+    step, and vice versa -- FusedAdam therefore carries torch.optim.Adam's full set of param-group keys.  (CPU: only
+    construction / state_dict / load_state_dict are exercised on the fused side; its step() needs a GPU.)"""
+    import torch
+    from g4splat_amd.optim import FusedAdam
+    mk = lambda: [{"params": [torch.nn.Parameter(torch.ones(5, 3))], "lr": 0.01, "name": "xyz"},
+                  {"params": [torch.nn.Parameter(torch.ones(5, 1))], "lr": 0.05, "name": "opacity"}]
+    fused = FusedAdam(mk(), lr=0.0, eps=1e-15)
+    ref = torch.optim.Adam(mk(), lr=0.0, eps=1e-15)
+    ref_keys = set(ref.state_dict()["param_groups"][0])
+    assert ref_keys <= set(fused.state_dict()["param_groups"][0]), ref_keys - set(fused.state_dict()["param_groups"][0])
+    # fused -> torch: populate a state, load, step
+    for g in fused.param_groups:
+        p = g["params"][0]
+        fused.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.full_like(p, 0.1), "exp_avg_sq": torch.full_like(p, 0.2)}
+    ref.load_state_dict(fused.state_dict())
+    for g in ref.param_groups:
+        g["params"][0].grad = torch.ones_like(g["params"][0])
+    ref.step()  # raised KeyError('weight_decay') before
+    assert float(ref.state[ref.param_groups[0]["params"][0]]["step"]) == 4.0
+    # torch -> fused
+    fused2 = FusedAdam(mk(), lr=0.0, eps=1e-15)
+    fused2.load_state_dict(ref.state_dict())
+    assert fused2.param_groups[0]["eps"] == 1e-15 and fused2.param_groups[1]["lr"] == 0.05
+    with pytest.raises(ValueError):
+        FusedAdam(mk(), weight_decay=0.1)
+    bad = ref.state_dict()
+    bad["param_groups"][0]["amsgrad"] = True
+    fused2.load_state_dict(bad)
+    fused2.param_groups[0]["params"][0].grad = torch.ones(5, 3)
+    with pytest.raises(ValueError):
+        fused2.step()  # non-default settings smuggled in through load_state_dict are refused at step()
+
+
+def test_debug_snapshot_covers_the_split_sh_node(tmp_path, monkeypatch):
+    """raster_settings.debug=True writes snapshot_fw.dump on a failing forward also on the split-SH path
+    (the one render() takes), with both SH tensors in it."""
+    import torch
+    from g4splat_amd import diff_surfel_rasterization as dsr
+    monkeypatch.chdir(tmp_path)
+
+    def boom(*a):
+        raise RuntimeError("injected failure")
+
+    monkeypatch.setattr(dsr._C, "rasterize_gaussians", boom)
+    P = 4
+    rs = dsr.GaussianRasterizationSettings(image_height=8, image_width=8, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3),
+                                           scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=1,
+                                           campos=torch.zeros(3), prefiltered=False, debug=True)
+    with pytest.raises(RuntimeError, match="injected"):
+        dsr.rasterize_gaussians(torch.zeros(P, 3), torch.zeros(P, 3), (torch.ones(P, 1, 3), torch.ones(P, 15, 3)), None,
+                                torch.ones(P, 1), torch.ones(P, 2), torch.ones(P, 4), torch.empty(0), rs)
+    dump = torch.load(tmp_path / "snapshot_fw.dump")
+    pair = [a for a in dump if isinstance(a, tuple)]
+    assert len(pair) == 1 and pair[0][0].shape == (P, 1, 3) and pair[0][1].shape == (P, 15, 3)
