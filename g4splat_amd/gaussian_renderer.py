@@ -18,11 +18,9 @@ from .diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRa
 from .render_maps import render_maps
 
 
-def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, rasterizer_cls=None,
-           maps_fn=None):
-    """Render one view.  `rasterizer_cls` / `maps_fn` (defaults: the HIP GaussianRasterizer and the HIP
-    `render_maps`) exist only so that the CPU test-suite can drive this function's host logic with the
-    oracle; the product path never passes them."""
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """Render one view (the reference's signature, :19).  The rasterizer and the map post-processing are the module
+    attributes `GaussianRasterizer` and `render_maps` (the HIP implementations; there is no CPU path)."""
     xyz = pc.get_xyz
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
     try:
@@ -35,7 +33,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-    rasterizer = (rasterizer_cls or GaussianRasterizer)(raster_settings=raster_settings)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     scales = rotations = cov3D_precomp = opacity = None
     if getattr(pipe, "compute_cov3D_python", False):
@@ -48,8 +46,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
         cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
     else:
-        # (the HIP model evaluates its three activations in one fused launch; the CPU checker path keeps the getters)
-        act = getattr(pc, "get_activated", None) if rasterizer_cls is None else None
+        # (a model on the HIP device evaluates its three activations in one fused launch)
+        act = getattr(pc, "get_activated", None) if xyz.is_cuda else None
         if act is not None:
             scales, rotations, opacity = act
         else:
@@ -60,7 +58,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         # convert_SHs_python is forced off in the reference (:82).  The reference concatenates the two SH parameter
         # tensors here (pc.get_features); the HIP rasterizer reads them where they are (split-SH entry points), which
         # saves the concatenation and the slicing of its gradient -- 4 x P x 192 B per iteration.
-        split = getattr(pc, "get_features_split", None) if rasterizer_cls is None else None
+        split = getattr(pc, "get_features_split", None) if xyz.is_cuda else None
         shs = split if split is not None else pc.get_features
     else:
         colors_precomp = override_color
@@ -71,7 +69,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}
 
-    rets.update((maps_fn or render_maps)(allmap, viewpoint_camera, pipe.depth_ratio))
+    rets.update(render_maps(allmap, viewpoint_camera, pipe.depth_ratio))
     return rets
 
 
@@ -96,8 +94,7 @@ class _JoinedModels:
         return torch.cat([pc.get_covariance(scaling_modifier) for pc in self._pcs], dim=0)
 
 
-def render_gslist(viewpoint_camera, pc_list, pipe, bg_color, scaling_modifier=1.0, override_color=None, rasterizer_cls=None,
-                  maps_fn=None):
+def render_gslist(viewpoint_camera, pc_list, pipe, bg_color, scaling_modifier=1.0, override_color=None):
     """2dgs/gaussian_renderer/__init__.py:169-363: the models of `pc_list` rendered together.  `override_color` may be
     a list with one tensor per model (:286-287).  Returns render()'s dictionary without the two `_cam` normal maps
     plus `model_start_indices` = [0, P_0, P_0 + P_1, ...] (:355-361)."""
@@ -105,8 +102,7 @@ def render_gslist(viewpoint_camera, pc_list, pipe, bg_color, scaling_modifier=1.
         raise ValueError("pc_list must be a list of GaussianModel objects")
     if isinstance(override_color, list):
         override_color = torch.cat(override_color, dim=0)
-    rets = render(viewpoint_camera, _JoinedModels(pc_list), pipe, bg_color, scaling_modifier, override_color,
-                  rasterizer_cls=rasterizer_cls, maps_fn=maps_fn)
+    rets = render(viewpoint_camera, _JoinedModels(pc_list), pipe, bg_color, scaling_modifier, override_color)
     rets.pop("rend_normal_cam", None)
     rets.pop("surf_normal_cam", None)
     starts = [0]

@@ -1,6 +1,8 @@
 """TEST INFRASTRUCTURE: an oracle-backed stand-in with the GaussianRasterizer interface, on CPU tensors.
 It lets the CPU suite exercise the host-side logic around the operator (render() post-processing, the
 data-parallel gradient exchange) where no GPU exists.  Never imported by the product."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -41,3 +43,19 @@ class OracleRasterizer(torch.nn.Module):
                                       e if colors_precomp is None else colors_precomp, opacities,
                                       e if scales is None else scales, e if rotations is None else rotations,
                                       e if cov3D_precomp is None else cov3D_precomp, self.raster_settings)
+
+
+@contextlib.contextmanager
+def oracle_backend():
+    """Inside the block `g4splat_amd.gaussian_renderer.render()` rasterizes with the CPU oracle and post-processes with
+    the plain-torch restatement -- the CPU suite's way to drive render()'s host logic (and, on the GPU box, to
+    produce the reference result the HIP render is compared with).  The product function has no hook for this: the
+    two module attributes it calls are swapped from the outside."""
+    from g4splat_amd import gaussian_renderer as gr
+    from oracle.render_maps_ref import render_maps as maps_ref
+    saved = gr.GaussianRasterizer, gr.render_maps
+    gr.GaussianRasterizer, gr.render_maps = OracleRasterizer, maps_ref
+    try:
+        yield
+    finally:
+        gr.GaussianRasterizer, gr.render_maps = saved

@@ -51,12 +51,12 @@ def _model(seed=0, P=150):
 
 
 def _step(model, views, vp):
-    from cpu_rasterizer import OracleRasterizer
-    from oracle.render_maps_ref import render_maps as maps_ref
+    from cpu_rasterizer import oracle_backend
     from g4splat_amd.gaussian_renderer import render
     pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False)
     for v in views:
-        out = render(v, model, pipe, torch.tensor([0.0, 0.1, 0.2]), rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+        with oracle_backend():
+            out = render(v, model, pipe, torch.tensor([0.0, 0.1, 0.2]))
         loss = (out["render"] ** 2).mean() + 0.1 * out["rend_dist"].mean() + 0.05 * out["rend_alpha"].mean()
         loss.backward()
         vp.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])

@@ -5,10 +5,10 @@ import numpy as np
 import pytest
 import torch
 
-from cpu_rasterizer import OracleRasterizer
+from cpu_rasterizer import oracle_backend
 from test_render_cpu import KEYS, _camera, _model
+from g4splat_amd import synthetic
 from g4splat_amd.gaussian_renderer import render
-from oracle.render_maps_ref import render_maps as maps_ref
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +29,8 @@ def _loss(out):
 def test_render_matches_oracle_driven_render(hip_lib):
     cam, pipe = _camera(), SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False)
     ref_model, hip_model = _model(seed=2), _model(seed=2)
-    ref = render(cam, ref_model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    with oracle_backend():
+        ref = render(cam, ref_model, pipe, torch.tensor([0.1, 0.2, 0.3]))
     _loss(ref).backward()
     dev = torch.device("cuda:0")
     for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
@@ -287,3 +288,35 @@ def test_wrong_element_counts_are_refused(hip_lib):
                       (dict(cam=z(2)), "campos")):
         with pytest.raises(RuntimeError, match=msg):
             call(**over)
+
+
+def test_scene_file_in_the_reference_layout_loads_and_renders(hip_lib):
+    """tests/golden/scene_ref_layout.ply (the reference's on-disk format, packed byte by byte by
+    tests/golden/make_golden_ply.py -- no code shared with ply_io.py; 200 surfels, SH degree 3, mip filter) is loaded
+    with GaussianModel.load_ply straight onto the GPU and rendered through render(); the result must equal the oracle-
+    driven render of the same file loaded on the host."""
+    import os
+    from g4splat_amd.gaussian_model import GaussianModel
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_ref_layout.ply")
+    dev = torch.device("cuda:0")
+    host, gpu = GaussianModel(3), GaussianModel(3)
+    host.load_ply(path, device="cpu")
+    gpu.load_ply(path)  # default device: "cuda", like the reference (:484-491)
+    assert gpu._xyz.is_cuda and gpu._xyz.shape == (200, 3) and gpu.use_mip_filter
+    W, H = 160, 112
+    c = synthetic.look_at_camera((0.1, 0.05, -0.2), (0.6, 0.1, 0.9), (0, 1, 0), 1.3, W, H)  # inside the 2 x 1.5 x 1.2 m box
+    cam = SimpleNamespace(image_width=W, image_height=H, FoVx=c.FoVx, FoVy=c.FoVy, znear=0.01, zfar=100.0,
+                          world_view_transform=torch.tensor(c.world_view_transform),
+                          full_proj_transform=torch.tensor(c.full_proj_transform), camera_center=torch.tensor(c.camera_center))
+    pipe = SimpleNamespace(depth_ratio=1.0, compute_cov3D_python=False)
+    bg = torch.tensor([0.2, 0.3, 0.1])
+    with oracle_backend():
+        ref = render(cam, host, pipe, bg)
+    out = render(_to(cam, dev), gpu, pipe, bg.to(dev))
+    assert int(ref["visibility_filter"].sum()) > 50
+    for k in KEYS - {"viewspace_points"}:
+        a, b = out[k].detach().cpu(), ref[k].detach()
+        if a.dtype.is_floating_point:
+            assert (a - b).abs().max() <= 2e-5, (k, float((a - b).abs().max()))
+        else:
+            assert torch.equal(a, b), k

@@ -13,13 +13,14 @@ import numpy as np
 import pytest
 import torch
 
-from cpu_rasterizer import OracleRasterizer
+import contextlib
+
+from cpu_rasterizer import oracle_backend
 from g4splat_amd import synthetic
 from g4splat_amd.gaussian_model import GaussianModel
 from g4splat_amd.gaussian_renderer import render
 from g4splat_amd.losses import photometric_loss
 from oracle import losses_ref
-from oracle.render_maps_ref import render_maps as maps_ref
 
 pytestmark = pytest.mark.gpu
 W, H, P, ITERS = 96, 64, 400, 40
@@ -64,11 +65,12 @@ def _train(dev, targets):
     model.training_setup()
     pipe = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
     bg = torch.tensor([0.0, 0.0, 0.0], device=dev)
-    kw = {} if hip else dict(rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    backend = contextlib.nullcontext if hip else oracle_backend  # CPU run: oracle rasterizer + torch maps
     losses = []
     for it in range(ITERS):
         cam, gt = cams[it % 4], targets[it % 4].to(dev)
-        out = render(cam, model, pipe, bg, **kw)
+        with backend():
+            out = render(cam, model, pipe, bg)
         if hip:
             loss, _l1, _s = photometric_loss(out["render"], gt, 0.2)
         else:
@@ -82,7 +84,8 @@ def _train(dev, targets):
             model.optimizer.zero_grad(set_to_none=True)
         losses.append(float(total.detach()))
     with torch.no_grad():
-        final = [render(c, model, pipe, bg, **kw)["render"].cpu() for c in cams]
+        with backend():
+            final = [render(c, model, pipe, bg)["render"].cpu() for c in cams]
     return np.array(losses), final, model
 
 
@@ -92,8 +95,8 @@ def test_hip_training_tracks_cpu_checker_training(hip_lib):
     pipe = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
     with torch.no_grad():
         truth = _model(0, cpu, jitter=False)
-        targets = [render(c, truth, pipe, torch.zeros(3), rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)["render"]
-                   for c in _cams(cpu)]
+        with oracle_backend():
+            targets = [render(c, truth, pipe, torch.zeros(3))["render"] for c in _cams(cpu)]
     l_cpu, f_cpu, m_cpu = _train(cpu, targets)
     l_gpu, f_gpu, m_gpu = _train(gpu, targets)
     assert l_cpu[-4:].mean() < 0.8 * l_cpu[:4].mean(), "the optimisation must make progress"

@@ -100,3 +100,27 @@ def test_empty_scene(tmp_path):
     n = GaussianModel(sh_degree=3)
     n.load_ply(path, device="cpu")
     assert n._xyz.shape == (0, 3) and n._features_rest.shape == (0, 15, 3)
+
+
+def test_reads_a_scene_file_built_byte_by_byte_in_the_reference_layout():
+    """tests/golden/scene_ref_layout.ply was packed with struct.pack, attribute by attribute, from the layout of
+    gaussian_model.py:276-315 (tests/golden/make_golden_ply.py shares no code with ply_io.py): the reader must return
+    exactly the arrays it was built from, and GaussianModel.load_ply the model the reference's load_ply (:441-493) builds."""
+    import os
+    import torch
+    from g4splat_amd.gaussian_model import GaussianModel
+    from g4splat_amd.ply_io import read_gaussian_ply
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(gold, "scene_ref_layout.npz"))
+    got = read_gaussian_ply(os.path.join(gold, "scene_ref_layout.ply"), 3)
+    for k in want.files:
+        assert got[k].dtype == np.float32 and got[k].shape == want[k].shape, k
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    m = GaussianModel(3)
+    m.load_ply(os.path.join(gold, "scene_ref_layout.ply"), device="cpu")
+    assert m.use_mip_filter and m.active_sh_degree == 3
+    assert torch.equal(m._features_rest.detach(), torch.tensor(want["features_rest"]))
+    assert m._features_dc.shape == (200, 1, 3) and m._features_rest.shape == (200, 15, 3)
+    # the activations the renderer sees (mip filter on): scaling^2 + filter^2, opacity rescaled
+    s = np.exp(want["scaling"])
+    np.testing.assert_allclose(m.get_scaling.detach().numpy(), np.sqrt(s * s + want["mip_filter"] ** 2), rtol=1e-6)

@@ -5,11 +5,20 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from cpu_rasterizer import OracleRasterizer
+import pytest
+
+from cpu_rasterizer import oracle_backend
 from g4splat_amd import synthetic
 from g4splat_amd.gaussian_model import GaussianModel
 from g4splat_amd.gaussian_renderer import render, render_gslist
-from oracle.render_maps_ref import depth_to_normal, render_maps as maps_ref
+from oracle.render_maps_ref import depth_to_normal
+
+
+@pytest.fixture(autouse=True)
+def _oracle_backend():
+    """Every render() of this module rasterizes with the CPU oracle (no GPU in the CPU suite)."""
+    with oracle_backend():
+        yield
 
 KEYS = {"render", "viewspace_points", "visibility_filter", "radii", "rend_alpha", "rend_normal", "rend_normal_cam",
         "rend_dist", "surf_depth", "surf_normal", "surf_normal_cam", "rend_depth"}
@@ -39,7 +48,7 @@ def _model(P=300, seed=0):
 def test_render_dict_and_gradients():
     cam, model = _camera(), _model()
     pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False, convert_SHs_python=False)
-    out = render(cam, model, pipe, torch.tensor([0.1, 0.2, 0.3]), rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    out = render(cam, model, pipe, torch.tensor([0.1, 0.2, 0.3]))
     assert set(out) == KEYS
     H, W = 56, 80
     assert out["render"].shape == (3, H, W) and out["rend_alpha"].shape == (1, H, W)
@@ -67,8 +76,8 @@ def test_python_cov3d_path_matches_kernel_path():
     cam, model = _camera(), _model(P=120, seed=3)
     model.get_covariance = lambda mod=1: _covariance(model, mod)
     bg = torch.zeros(3)
-    a = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False), bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
-    b = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=True), bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    a = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False), bg)
+    b = render(cam, model, SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=True), bg)
     assert torch.allclose(a["render"], b["render"], atol=2e-4)
     assert torch.allclose(a["rend_alpha"], b["rend_alpha"], atol=2e-4)
 
@@ -107,14 +116,14 @@ def test_render_gslist_equals_render_of_the_union():
     a, b = _model(P=120, seed=5), _model(P=80, seed=6)
     pipe = SimpleNamespace(depth_ratio=0.5, compute_cov3D_python=False)
     bg = torch.tensor([0.2, 0.1, 0.3])
-    out = render_gslist(cam, [a, b], pipe, bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    out = render_gslist(cam, [a, b], pipe, bg)
     assert set(out) == (KEYS - {"rend_normal_cam", "surf_normal_cam"}) | {"model_start_indices"}
     assert out["model_start_indices"] == [0, 120, 200]
     both = _model(P=200, seed=0)
     with torch.no_grad():
         for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
             getattr(both, name).copy_(torch.cat([getattr(a, name), getattr(b, name)], dim=0))
-    ref = render(cam, both, pipe, bg, rasterizer_cls=OracleRasterizer, maps_fn=maps_ref)
+    ref = render(cam, both, pipe, bg)
     for k in ("render", "rend_alpha", "rend_normal", "surf_depth", "surf_normal", "rend_dist", "rend_depth", "radii"):
         assert torch.equal(out[k], ref[k]), k
     (out["render"].mean() + out["rend_dist"].mean()).backward()
