@@ -37,6 +37,8 @@ WORKLOADS = {
     "s5": (3_000_000, 1200, 680, 3, 8),    # DeepBlending-like, configs[4]
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIMDS = 1024           # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # engine clock
 
 
 def build_scene(name, device):
@@ -235,12 +237,43 @@ def main():
         views = [(0 + i * world) % len(dcams) for i in range(args.steps)]
         Vm = sum(Vs[c] for c in views) / len(views)
         Rm = sum(Rs[c] for c in views) / len(views)
-        B = algorithmic_bytes(dom, P, Vm, Rm, N, (D + 1) ** 2, 16, tiles, tile_bits)
+        K = (D + 1) ** 2
+        B = algorithmic_bytes(dom, P, Vm, Rm, N, K, 16, tiles, tile_bits)
         achieved = B / (kernels_ms[dom] * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload, dom),
+        # What binds the kernel.  `achieved` / `peak` / `frac` are the contract's HBM figures (SURVEY.md 8(d) bytes of
+        # one launch / its HIP-event duration, measured in this run).  The blend kernels are NOT bound by HBM but by
+        # VALU issue: `valu` says so with numbers -- wave-level VALU instructions per launch come from the committed
+        # rocprofv3 PMC passes of this build (they cannot be read in-process; `source` names the file and the commit it
+        # was taken at), the duration is this run's.
+        pmc = pmc_profile(args.workload)
+        pk = (pmc or {}).get("kernels", {}).get(dom)
+        valu = None
+        if pk and "SQ_INSTS_VALU" in pk:
+            insts = float(pk["SQ_INSTS_VALU"])
+            t = kernels_ms[dom] * 1e-3
+            valu = {"wave_instructions_per_launch": int(insts),
+                    # share of the SIMDs' issue cycles one launch uses: every wave64 VALU instruction holds its SIMD
+                    # for 4 cycles; 1024 SIMDs at the 2.4 GHz engine clock (MI355X_MICROARCH.md)
+                    "issue_frac_this_run": round(insts * 4.0 / (SIMDS * CLOCK_HZ * t), 4),
+                    "assumes": f"{SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz, 4 cycles per wave64 VALU instruction",
+                    # the same ratio with the cycle count of the profiled launch itself (no clock assumption)
+                    "issue_frac_profiled": (round(insts * 4.0 / (pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS), 4)
+                                            if pk.get("GRBM_GUI_ACTIVE") else None)}
+        bound = "valu" if valu and valu["issue_frac_this_run"] > achieved / HBM_PEAK_GBS else "hbm"
+        traffic = int((2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024) if pk and "FETCH_SIZE" in pk and "WRITE_SIZE" in pk else None
+        # whole step against the HBM roofline: every kernel's 8(d) bytes / the step time of this run
+        B_step = (P * 60 + Vm * (12 * K + 76) + Rm * 12 + Rm * 24 * ((tile_bits + 7) // 8) + Rm * 8 + tiles * 8
+                  + 2 * (Rm * 76 + N * 60) + Vm * 72 + Vm * (44 + 12 * K + 72 + 36 + 3) + P * 52 + P * 12 * 16 + Vm * 12 * K)
+        step_ms = elapsed / args.steps * 1e3
+        roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": (pmc or {}).get("provenance"),
                     "algorithmic_bytes_per_launch": int(B), "avg_launch_ms": round(kernels_ms[dom], 4),
-                    "valu": pmc_valu(args.workload, dom)}
+                    "valu": valu,
+                    "whole_step": {"algorithmic_bytes": int(B_step), "GBps": round(B_step / (step_ms * 1e-3) / 1e9, 1),
+                                   "frac_of_hbm_peak": round(B_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "SURVEY.md 8(d) bytes of all kernels (reference algorithm: 64-bit-key sort over "
+                                           "all instances) / this run's step time"}}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
@@ -271,29 +304,23 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic_<workload>.json,
-    FETCH_SIZE and WRITE_SIZE collected in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950).  None if no profile of this workload is committed."""
-    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
-    try:
-        k = json.load(open(path))["kernels"][kernel]
-        return int((2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)
-    except Exception:
-        return None
-
-
-def pmc_valu(workload, kernel):
-    """What actually bounds the blend kernels: VALU issue.  From the same committed PMC passes: wave-level VALU
-    instructions per launch and SIMD cycles per instruction (GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs;
-    a wave64 VALU instruction occupies its SIMD for 4 cycles, so ~4 means the SIMDs do nothing but issue)."""
-    path = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
-    try:
-        k = json.load(open(path))["kernels"][kernel]
-        return {"wave_instructions_per_launch": int(k["SQ_INSTS_VALU"]),
-                "simd_cycles_per_wave_instruction": round(k["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / k["SQ_INSTS_VALU"], 2)}
-    except Exception:
-        return None
+def pmc_profile(workload):
+    """The committed rocprofv3 PMC summary of this workload (profiles/r<NN>_traffic_<workload>.json, newest round
+    first; written by tools/profile_gpu.sh + tools/summarize_prof.py on the GPU box): FETCH_SIZE / WRITE_SIZE in KiB
+    (separate passes; HBM bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md),
+    SQ_INSTS_VALU and GRBM_GUI_ACTIVE per launch.  These counters cannot be collected inside this process, so the
+    bench line labels them with `provenance` (file + the commit the profiled library was built from)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{workload}.json")), reverse=True)
+    cands.append(os.path.join(ROOT, "profiles", f"traffic_{workload}.json"))
+    for path in cands:
+        try:
+            d = json.load(open(path))
+            d.setdefault("provenance", f"{os.path.relpath(path, ROOT)} (static: rocprofv3 --pmc passes, not measured in this run)")
+            return d
+        except Exception:
+            continue
+    return None
 
 
 def run_cpu_baseline(scene, cam, P, W, H, D, target_gaussians=150_000, target_seconds=15.0):
@@ -327,8 +354,9 @@ def _cpu_baseline_once(scene, cam, P, W, H, D, target_gaussians):
     dt = time.perf_counter() - t0
     V = int((radii > 0).sum())
     return {"seconds": dt, "value": V / dt, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} of {P} surfels (seeded subset), same view 0 at {W}x{H}, 1 fwd+bwd, "
-                      f"{V} visible, {R} instances, {dt:.2f} s, OpenMP over all host cores"}
+            "sample": f"workload of this line, bounded: {n} of {P} surfels (seeded subset), same view 0 at {W}x{H}, 1 fwd+bwd, "
+                      f"{V} visible, {R} instances, {dt:.2f} s, OpenMP over all host cores (oracle/surfel_oracle.c; "
+                      f"SURVEY.md 8(d) asks for S1/S2: run --workload s1 / s2 for those)"}
 
 
 if __name__ == "__main__":

@@ -190,8 +190,19 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     return G4S_OK;
 }
 
-// shs_rest == NULL: shs is the packed [P,M,3] tensor; otherwise shs = [P,1,3] and shs_rest = [P,M-1,3]
+// Fixed buffers as "resize callbacks" (g4s_rasterizer_forward_presized): the callback hands the caller's chunk out
+// if it is large enough.
+struct FixedChunk { char* ptr; size_t bytes; };
+char* fixed_chunk_cb(void* ctx, size_t n) {
+    FixedChunk* c = (FixedChunk*)ctx;
+    return n <= c->bytes ? c->ptr : nullptr;
+}
+
+// shs_rest == NULL: shs is the packed [P,M,3] tensor; otherwise shs = [P,1,3] and shs_rest = [P,M-1,3].
+// capacity >= 0: the presized, host-synchronisation-free form -- the binning chunk holds `capacity` instances, the
+// instance counts stay on the device (status_dev), nothing is read back.
 static int rasterizer_forward_impl(
+    int capacity, uint32_t* status_dev,
     g4s_resize_fn geometry_buffer, void* geometry_ctx, g4s_resize_fn binning_buffer, void* binning_ctx,
     g4s_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,
     const float* means3D, const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
@@ -222,6 +233,8 @@ static int rasterizer_forward_impl(
     float* final_T = (float*)(img + IL.final_T);
     uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
     if (P <= 0) HIP_TRY(hipMemsetAsync(ranges, 0, (size_t)tiles * 8, stream));  // rasterizer_impl.cu:311 (P > 0: cleared by the totals scan)
+    const bool presized = capacity >= 0;
+    if (presized && status_dev && P <= 0) HIP_TRY(hipMemsetAsync(status_dev, 0, 16, stream));
 
     int R = 0;
     const float* rec_ptr = nullptr;
@@ -276,14 +289,25 @@ static int rasterizer_forward_impl(
         uint32_t* vis_block_offs = (uint32_t*)(geom + GL.vis_block_offs);
         { ProfScope ps(PF_COUNT_SCAN, stream);
           launch_scan_totals(pa.idx_block_sums, idx_block_offs, pa.ref_block_sums, pa.vis_block_sums, vis_block_offs,
-                             d_total, GL.nblocks, ranges, tiles * 2, stream); }
+                             d_total, GL.nblocks, ranges, tiles * 2, stream, presized ? (uint32_t)capacity : 0xFFFFFFFFu); }
         CHECK_LAUNCH("scan totals");
-        uint32_t* h_total = pinned_word();
-        if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
-        hipEvent_t totals_ready = readback_event();
-        if (!totals_ready) return fail(G4S_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipMemcpyAsync(h_total, d_total, 12, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipEventRecord(totals_ready, stream));
+        uint32_t* h_total = nullptr;
+        hipEvent_t totals_ready = nullptr;
+        if (!presized) {
+            h_total = pinned_word();
+            if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
+            totals_ready = readback_event();
+            if (!totals_ready) return fail(G4S_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipMemcpyAsync(h_total, d_total, 12, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(totals_ready, stream));
+        } else if (status_dev) {
+            // status[0] = num_rendered (the reference's count), [1] = instances binned, [2] = emitting Gaussians,
+            // [3] = 1 if the binned instances exceed `capacity` (the frame is then incomplete)
+            HIP_TRY(hipMemcpyAsync(status_dev, d_total + 1, 4, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(status_dev + 1, d_total, 4, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(status_dev + 2, d_total + 2, 4, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(status_dev + 3, d_total + 4, 4, hipMemcpyDeviceToDevice, stream));
+        }
 
         // Queued BEFORE the host waits for the totals: nothing below needs them on the host -- the gradient slots do
         // not depend on them, and the pack / depth sort / count of the emitting Gaussians read V (d_total[2]) on the
@@ -304,26 +328,40 @@ static int rasterizer_forward_impl(
         CHECK_LAUNCH("depth sort");
         {
             ProfScope ps(PF_COUNT_SCAN, stream);
-            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, rank_local, d_total + 4, GL.nblocks,
+            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, rank_local, d_total + 8, GL.nblocks,
                               stream, d_V);
         }
         CHECK_LAUNCH("count scan");
 
-        // the one host wait of the forward (rasterizer_impl.cu:281-282), on the read-back only
-        HIP_TRY(hipEventSynchronize(totals_ready));
-        // h_total[0]: instances actually binned (3-sigma rect intersected with the alpha-cutoff box),
-        // h_total[1]: the reference's count (3-sigma rect only) = the num_rendered this call returns,
-        // h_total[2]: Gaussians that emit at least one instance.
-        // All buffers are laid out for the reference count, which bounds the binned one.
-        if (h_total[1] > 0x7FFFFFFFu) return fail(G4S_ERR_INVALID_ARGUMENT, "num_rendered overflows int");
-        R = (int)h_total[1];
-        const int R_binned = (int)h_total[0];
-        const int V_emit = (int)h_total[2];
-        const int nblocks_v = (V_emit + 255) / 256;
+        int R_binned, V_emit, nblocks_v;
+        const uint32_t* d_counts = nullptr;   // presized: (V, min(binned, capacity)) on the device
+        const uint32_t* d_nbinned = nullptr;
+        if (!presized) {
+            // the one host wait of the forward (rasterizer_impl.cu:281-282), on the read-back only
+            HIP_TRY(hipEventSynchronize(totals_ready));
+            // h_total[0]: instances actually binned (3-sigma rect intersected with the alpha-cutoff box),
+            // h_total[1]: the reference's count (3-sigma rect only) = the num_rendered this call returns,
+            // h_total[2]: Gaussians that emit at least one instance.
+            // All buffers are laid out for the reference count, which bounds the binned one.
+            if (h_total[1] > 0x7FFFFFFFu) return fail(G4S_ERR_INVALID_ARGUMENT, "num_rendered overflows int");
+            R = (int)h_total[1];
+            R_binned = (int)h_total[0];
+            V_emit = (int)h_total[2];
+            nblocks_v = (V_emit + 255) / 256;
+        } else {
+            // no read-back: every launch below is sized for the capacity and reads the counts on the device
+            R = capacity;  // what the layouts (here and in the backward) are computed from
+            R_binned = capacity;
+            V_emit = P;
+            nblocks_v = GL.nblocks;
+            d_counts = d_total + 2;
+            d_nbinned = d_total + 3;
+        }
 
         const BinLayout BL = bin_layout((size_t)R);
         char* bin = binning_buffer(binning_ctx, BL.bytes);
-        if (!bin) return fail(G4S_ERR_ALLOC, "binning buffer callback returned NULL");
+        if (!bin) return fail(G4S_ERR_ALLOC, presized ? "binning buffer smaller than g4s_rasterizer_layout(P, capacity).binning_bytes"
+                                                      : "binning buffer callback returned NULL");
         bin = align_ptr(bin);
         uint64_t* ent_a = (uint64_t*)(bin + BL.ent_a);
         uint64_t* ent_b = (uint64_t*)(bin + BL.ent_b);
@@ -332,16 +370,16 @@ static int rasterizer_forward_impl(
         if (R_binned > 0) {
             { ProfScope ps(PF_EMIT, stream);  // (also clears the contribution masks qhit[0, R_binned))
               launch_emit(V_emit, (uint32_t)R_binned, tiles_x, tiles_y, gidx_sorted, block_offs, nblocks_v, rank_local,
-                          radii, rec, ent_a, qhit_ptr, stream); }
+                          radii, rec, ent_a, qhit_ptr, stream, d_counts); }
             CHECK_LAUNCH("emit");
             const int tile_bits = tile_sort_bits(tiles);  // rasterizer_impl.cu:301
             int c2;
             { ProfScope ps(PF_TILE_SORT, stream);
               c2 = radix_sort_u64_keys(ent_a, ent_b, R_binned, ENTRY_TILE_SHIFT, ENTRY_TILE_SHIFT + tile_bits,
-                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total), stream); }
+                                       (uint32_t*)(bin + BL.hist), (uint32_t*)(bin + BL.bin_total), stream, d_nbinned); }
             CHECK_LAUNCH("tile partition");
             entries_ptr = c2 ? ent_b : ent_a;
-            { ProfScope ps(PF_TILE_RANGES, stream); launch_tile_ranges(R_binned, entries_ptr, ranges, stream); }
+            { ProfScope ps(PF_TILE_RANGES, stream); launch_tile_ranges(R_binned, entries_ptr, ranges, stream, d_nbinned); }
             CHECK_LAUNCH("tile ranges");
         }
         rec_ptr = rec;
@@ -374,7 +412,7 @@ extern "C" int g4s_rasterizer_forward(
     float scale_modifier, const float* rotations, const float* transMat_precomp, const float* viewmatrix,
     const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
     float* out_others, int* radii, int debug, void* stream) {
-    return rasterizer_forward_impl(geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D,
+    return rasterizer_forward_impl(-1, nullptr, geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D,
                                    M, background, width, height, means3D, shs, nullptr, colors_precomp, opacities, scales,
                                    scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx,
                                    tan_fovy, prefiltered, out_color, out_others, radii, debug, stream);
@@ -391,16 +429,36 @@ extern "C" int g4s_rasterizer_forward_split_sh(
     if (P > 0 && (!sh_dc || M < 1 || (M > 1 && !sh_rest)))
         return fail(G4S_ERR_INVALID_ARGUMENT, "split SH needs sh_dc [P,1,3] and, for M > 1, sh_rest [P,M-1,3]");
     // M == 1: there is no rest tensor; the packed layout [P,1,3] is the same memory
-    return rasterizer_forward_impl(geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D,
+    return rasterizer_forward_impl(-1, nullptr, geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D,
                                    M, background, width, height, means3D, sh_dc, M > 1 ? sh_rest : nullptr, nullptr, opacities,
                                    scales, scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, cam_pos,
                                    tan_fovx, tan_fovy, prefiltered, out_color, out_others, radii, debug, stream);
 }
 
+// The forward without its host synchronisation (include/g4s_rasterizer.h).  sh_rest == NULL: packed SH.
+extern "C" int g4s_rasterizer_forward_presized(
+    char* geom_buffer, size_t geom_bytes, char* binning_buffer, size_t binning_bytes, char* image_buffer, size_t image_bytes,
+    int instance_capacity, uint32_t* status_dev, int P, int D, int M, const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* sh_rest, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+    float* out_color, float* out_others, int* radii, int debug, void* stream) {
+    t_err[0] = 0;
+    if (instance_capacity < 0 || !status_dev) return fail(G4S_ERR_INVALID_ARGUMENT, "capacity must be >= 0 and status_dev non-NULL");
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(G4S_ERR_INVALID_ARGUMENT, "state buffers must not be NULL");
+    FixedChunk g{geom_buffer, geom_bytes}, b{binning_buffer, binning_bytes}, im{image_buffer, image_bytes};
+    const int rc = rasterizer_forward_impl(instance_capacity, status_dev, fixed_chunk_cb, &g, fixed_chunk_cb, &b, fixed_chunk_cb,
+                                           &im, P, D, M, background, width, height, means3D, shs, (M > 1 ? sh_rest : nullptr),
+                                           colors_precomp, opacities, scales, scale_modifier, rotations, transMat_precomp,
+                                           viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_others, radii,
+                                           debug, stream);
+    return rc < 0 ? rc : G4S_OK;  // (the impl returns the capacity as "R"; the real count is status_dev[0])
+}
+
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
-    // gradient records | folded per-Gaussian sums | one validity byte per record | deep-tile counter + list
-    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + align_up((size_t)(P > 0 ? P : 1) * GRAD_FLOATS * 4) +
-           align_up((size_t)(R > 0 ? R : 1)) + 256 + 65536 * 4 + 256;
+    // gradient records | one validity byte per record | deep-tile counter + list
+    (void)P;
+    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + align_up((size_t)(R > 0 ? R : 1)) + 256 + 65536 * 4 + 256;
 }
 
 static int rasterizer_backward_impl(
@@ -442,8 +500,7 @@ static int rasterizer_backward_impl(
     // its gather, K8b writes the others: no memset of the 192 B x P tensor)
     // gradient records: only instances that receive a contribution are written by the blend backward; instead of
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
-    float* gsum = (float*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));
-    uint8_t* rec_flag = (uint8_t*)gsum + align_up((size_t)P * GRAD_FLOATS * 4);
+    uint8_t* rec_flag = (uint8_t*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4);
     // the deep-tile counter sits right behind the validity bytes so that one memset clears both
     uint32_t* hot_count = (uint32_t*)(rec_flag + align_up((size_t)(R > 0 ? R : 1)));
     uint32_t* hot_list = hot_count + 64;
@@ -492,7 +549,7 @@ static int rasterizer_backward_impl(
     pb.transMat_precomp = transMat_precomp; pb.colors_precomp = colors_precomp;
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
-    pb.gsum = gsum; pb.rec_flag = rec_flag;
+    pb.rec_flag = rec_flag;
     pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest;
     pb.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;

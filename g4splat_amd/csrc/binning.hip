@@ -202,14 +202,14 @@ int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
 }
 
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
-                        uint32_t* bin_total, hipStream_t s) {
+                        uint32_t* bin_total, hipStream_t s, const uint32_t* d_n) {
     if (n <= 0) return 0;
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         if (cur == 0)
-            radix_pass<uint64_t, false, SORT_ITEMS_U64>(a, b, nullptr, nullptr, n, shift, hist, bin_total, s);
+            radix_pass<uint64_t, false, SORT_ITEMS_U64>(a, b, nullptr, nullptr, n, shift, hist, bin_total, s, d_n);
         else
-            radix_pass<uint64_t, false, SORT_ITEMS_U64>(b, a, nullptr, nullptr, n, shift, hist, bin_total, s);
+            radix_pass<uint64_t, false, SORT_ITEMS_U64>(b, a, nullptr, nullptr, n, shift, hist, bin_total, s, d_n);
         cur ^= 1;
     }
     return cur;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
                                                                const uint32_t* __restrict__ ref_sums,
                                                                uint32_t* __restrict__ total_a, uint32_t* __restrict__ total_b,
                                                                uint32_t* __restrict__ zero_ptr, int zero_words,
-                                                               const uint32_t* __restrict__ d_n) {
+                                                               const uint32_t* __restrict__ d_n, uint32_t capacity) {
     __shared__ uint32_t wa[16], wb[16], wr[16];
     const int t = (int)threadIdx.x;
     for (int i = t; i < zero_words; i += 1024) zero_ptr[i] = 0u;
@@ -285,7 +285,12 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
     if (t == 0) {
         total_a[0] = all_a;
         total_a[1] = all_r;
-        if (b_sums) total_b[0] = all_b;
+        if (b_sums) {
+            total_b[0] = all_b;
+            // (presized forward) total_b[1] = instances that fit the caller's binning capacity, total_b[2] = overflow flag
+            total_b[1] = all_a < capacity ? all_a : capacity;
+            total_b[2] = all_a > capacity ? 1u : 0u;
+        }
     }
 }
 
@@ -297,7 +302,7 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
                        block_sums, rank_local, d_n);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, total, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, 0, d_n);
+                       (uint32_t*)nullptr, 0, d_n, 0xFFFFFFFFu);
 }
 
 // Load-balanced expansion, partitioned by OUTPUT: a block owns EMIT_SLOTS consecutive instance slots, whatever
@@ -309,19 +314,29 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
 // produces output slots: a binary search in the LDS offsets, one coalesced 8-byte store per slot.
 // The block also clears its slots of the forward's contribution masks (qhit), which saves a memset launch.
 constexpr int EMIT_SLOTS = 1024;
+// d_counts != NULL (g4s_rasterizer_forward_presized: the host never learns the counts): V = d_counts[0] emitting
+// Gaussians, R_b = d_counts[1] instances (already clamped to the caller's capacity); the grid is sized for the
+// capacity and surplus blocks leave.
 __global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tiles_x, int tiles_y,
                                                    const uint32_t* __restrict__ gidx,
                                                    const uint32_t* __restrict__ block_offs, int nblocks_v,
                                                    const uint32_t* __restrict__ rank_local,
                                                    const int* __restrict__ radii, const float* __restrict__ rec,
-                                                   uint64_t* __restrict__ entries, uint8_t* __restrict__ qhit) {
+                                                   uint64_t* __restrict__ entries, uint8_t* __restrict__ qhit,
+                                                   const uint32_t* __restrict__ d_counts) {
     __shared__ uint32_t s_off[EMIT_SLOTS + 4];  // first slot of the staged ranks (ascending), then a sentinel
     __shared__ uint32_t s_idx[EMIT_SLOTS + 4];
     __shared__ uint32_t s_rect[EMIT_SLOTS + 4];   // x0 | y0 << 16
     __shared__ uint32_t s_rect2[EMIT_SLOTS + 4];  // rect width in tiles
     __shared__ uint32_t s_nr;
     const int t = (int)threadIdx.x;
+    if (d_counts != nullptr) {
+        V = (int)d_counts[0];
+        R_b = d_counts[1];
+        nblocks_v = (V + 255) / 256;
+    }
     const uint32_t w0 = blockIdx.x * (uint32_t)EMIT_SLOTS;
+    if (w0 >= R_b) return;  // (uniform)
     const uint32_t w1 = min(w0 + (uint32_t)EMIT_SLOTS, R_b);
     // contribution masks of this window (bytes [w0, w1)); w0 is a multiple of 1024, the array base 256-B aligned
     {
@@ -419,25 +434,27 @@ void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32
 
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
-                        uint32_t* zero_ptr, int zero_words, hipStream_t s) {
-    // total[0] = instances binned, total[1] = the reference's num_rendered, total[2] = emitting Gaussians
+                        uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity) {
+    // total[0] = instances binned, total[1] = the reference's num_rendered, total[2] = emitting Gaussians,
+    // total[3] = min(total[0], capacity), total[4] = 1 if total[0] > capacity
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
                        vis_block_sums, vis_block_offs, ref_block_sums, total, total + 2, zero_ptr, zero_words,
-                       (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, capacity);
 }
 
 void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
                  int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
-                 uint8_t* qhit, hipStream_t s) {
-    if (R_b == 0) return;
+                 uint8_t* qhit, hipStream_t s, const uint32_t* d_counts) {
+    if (R_b == 0) return;  // (d_counts != NULL: R_b is the capacity the grid is sized for)
     hipLaunchKernelGGL(emit_kernel, dim3((R_b + EMIT_SLOTS - 1) / EMIT_SLOTS), dim3(256), 0, s, V, R_b, tiles_x, tiles_y,
-                       gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit);
+                       gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit, d_counts);
 }
 
 // rasterizer_impl.cu:116-138 on the packed entries (ranges pre-zeroed by the caller, :311)
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int R, const uint64_t* __restrict__ entries,
-                                                          uint32_t* __restrict__ ranges) {
+                                                          uint32_t* __restrict__ ranges, const uint32_t* __restrict__ d_n) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (d_n != nullptr) R = (int)*d_n;
     if (i >= R) return;
     const uint32_t cur = entry_tile(entries[i]);
     if (i == 0) {
@@ -492,9 +509,9 @@ void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, 
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, ranges, tile_order);
 }
 
-void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s) {
+void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s, const uint32_t* d_n) {
     if (R <= 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, entries, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, entries, ranges, d_n);
 }
 
 }  // namespace g4s

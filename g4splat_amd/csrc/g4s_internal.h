@@ -141,7 +141,7 @@ int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
                          uint32_t* hist, uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr);
 // 64-bit keys-only over bits [begin_bit, end_bit).
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
-                        uint32_t* bin_total, hipStream_t s);
+                        uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr);
 
 // Exclusive scan (in depth order) of tiles_touched: block_offs[r >> 8] + rank_local[r] = first output slot of depth
 // rank r; total[0] = instances binned.
@@ -153,7 +153,7 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
 // total[2] = number of emitting Gaussians.  Also clears zero_words 32-bit words at zero_ptr (the tile ranges).
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
-                        uint32_t* zero_ptr, int zero_words, hipStream_t s);
+                        uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity = 0xFFFFFFFFu);
 // Index-order pass: gradient-record slots (rec[idx].inst_off = exclusive scan of tiles_touched over idx) and the
 // stable compaction of the emitting Gaussians' (depth key, index) pairs.
 void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec,
@@ -162,8 +162,8 @@ void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32
 // Instances in depth order, R_b of them; also clears qhit[0, R_b).
 void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
                  int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
-                 uint8_t* qhit, hipStream_t s);
-void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s);
+                 uint8_t* qhit, hipStream_t s, const uint32_t* d_counts = nullptr);
+void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s, const uint32_t* d_n = nullptr);
 // Longest-list-first processing order of the tiles (work balance of the blend kernels).
 void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s);
 
@@ -219,7 +219,6 @@ struct PreprocessBwdArgs {
     const uint8_t* clamped;
     const float* grad_inst;
     const uint8_t* rec_flag;
-    float* gsum;  // P x 18 folded gradient terms (workspace)
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
     const float* shs_rest;  // split layout: shs / dL_dsh are the [P,1,3] parts, shs_rest / dL_dsh_rest the [P,M-1,3] ones
     float* dL_dsh_rest;

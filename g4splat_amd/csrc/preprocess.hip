@@ -584,8 +584,7 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
 // Gaussian.  Every output element is written (zeros for invisible Gaussians).
 constexpr int K8_SUM_STRIDE = GRAD_FLOATS + 1;  // LDS row stride, odd => conflict-free column reads
 
-// K8a: fold only (few registers => full occupancy for a latency-bound gather); the per-Gaussian
-// sums go to gsum[P][18] with coalesced stores.
+// K8, phase 1: the fold.
 //
 // A ROW of 16 lanes folds one Gaussian, four Gaussians per wave at a time, two such groups in flight: lane (kk, c)
 // of a row reads quad c of record 4 s + kk, s = 0, 1, ... -- a typical run of ~10 records is three steps, all

@@ -150,6 +150,72 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return rendered, out_color, out_others, radii, geom.tensor, binning.tensor, img.tensor
 
 
+class PresizedState:
+    """Caller-owned chunks for `rasterize_gaussians_presized` (extension: g4s_rasterizer_forward_presized), reusable
+    from frame to frame: no allocation and no host synchronisation per forward.  `instance_capacity` bounds the
+    binned (Gaussian, tile) instances of a frame; `status` is the device tensor [num_rendered, instances binned,
+    emitting Gaussians, overflow flag] the library fills -- reading it (`.tolist()`) is the caller's decision."""
+
+    def __init__(self, P, width, height, instance_capacity, device):
+        lib = _lib.load()
+        L = _lib.G4sLayout()
+        if lib.g4s_rasterizer_layout(int(P), int(instance_capacity), int(width), int(height), ctypes.byref(L)) != 0:
+            _raise(-1, "g4s_rasterizer_layout")
+        self.P, self.width, self.height, self.capacity = int(P), int(width), int(height), int(instance_capacity)
+        mk = lambda n: torch.empty(int(n), dtype=torch.uint8, device=device)
+        self.geom, self.binning, self.img = mk(L.geom_bytes), mk(L.binning_bytes), mk(L.image_bytes)
+        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+
+
+def rasterize_gaussians_presized(state, background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                 transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
+                                 sh, degree, campos, prefiltered, debug):
+    """`rasterize_gaussians` without the read-back of num_rendered: same arguments after `state` (a PresizedState), same
+    outputs -- except that the first element of the returned tuple is the CAPACITY (pass it as `R` to
+    rasterize_gaussians_backward); the real counts are in `state.status` on the device.  The host never waits."""
+    if means3D.ndim != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    split = isinstance(sh, (tuple, list))
+    sh_dc, sh_rest = sh if split else (sh, None)
+    for name, t in (("background", background), ("means3D", means3D), ("colors", colors), ("opacity", opacity),
+                    ("scales", scales), ("rotations", rotations), ("transMat_precomp", transMat_precomp),
+                    ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("sh", sh_dc), ("campos", campos)) + (
+                        (("sh_rest", sh_rest),) if split else ()):
+        _check_cuda(t, name)
+    if split:
+        _check_split_sh(sh_dc, sh_rest, means3D, colors)
+    lib = _lib.load()
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    if (P, W, H) != (state.P, state.width, state.height):
+        raise RuntimeError(f"PresizedState was built for P={state.P}, {state.width}x{state.height}")
+    _check_shapes(P, background, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh, campos)
+    dev = means3D.device
+    with torch.cuda.device(dev):
+        fopt = dict(dtype=torch.float32, device=dev)
+        out_color = torch.empty((NUM_CHANNELS, H, W), **fopt)
+        out_others = torch.empty((7, H, W), **fopt)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        bg, m3, col, opa = _f32c(background), _f32c(means3D), _f32c(colors), _f32c(opacity)
+        sc, rot, tm = _f32c(scales, 8), _f32c(rotations, 16), _f32c(transMat_precomp)
+        vm, pm, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if split:
+            M = 1 + int(sh_rest.size(1))
+            shc, rest = _f32c(sh_dc), _f32c(sh_rest)
+        else:
+            M = int(sh.size(1)) if sh.size(0) != 0 else 0
+            shc, rest = _f32c(sh, 16), None
+        rc = lib.g4s_rasterizer_forward_presized(
+            _ptr(state.geom), state.geom.numel(), _ptr(state.binning), state.binning.numel(), _ptr(state.img),
+            state.img.numel(), state.capacity, _ptr(state.status), P, int(degree), M, _ptr(bg), W, H, _ptr(m3), _ptr(shc),
+            _ptr(rest), _ptr(col), _ptr(opa), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm),
+            _ptr(cp), float(tan_fovx), float(tan_fovy), _ptr(out_color), _ptr(out_others), _ptr(radii), int(bool(debug)),
+            stream)
+        if rc < 0:
+            _raise(rc, "rasterize_gaussians_presized")
+    return state.capacity, out_color, out_others, radii, state.geom, state.binning, state.img
+
+
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  transMat_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_others, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,

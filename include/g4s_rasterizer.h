@@ -85,7 +85,7 @@ int g4s_rasterizer_forward(
     float* out_color, float* out_others, int* radii, int debug, void* stream);
 
 /* Bytes of transient workspace g4s_rasterizer_backward needs for a forward that
- * returned R (per-instance gradient records, 80 B each, + 72 B per Gaussian + alignment). */
+ * returned R (per-instance gradient records, 80 B + one validity byte each, + a 256 KB tile list). */
 size_t g4s_rasterizer_backward_workspace(int P, int R);
 
 /*
@@ -149,6 +149,36 @@ int g4s_rasterizer_backward_split_sh(
     float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale, float* dL_drot,
     char* workspace, size_t workspace_bytes, int debug, void* stream);
+
+/*
+ * The forward WITHOUT its host synchronisation (extension; same results as g4s_rasterizer_forward[_split_sh]).
+ * The reference -- and the two entry points above -- read num_rendered back to size the binning chunk
+ * (rasterizer_impl.cu:281-282): the host stalls until the GPU has drained everything queued before the call, every
+ * frame.  Here the caller fixes the chunks up front:
+ *
+ *   instance_capacity : the largest number of binned (Gaussian, tile) instances the call may produce
+ *   geom / binning / image buffers : at least the geom_bytes / binning_bytes / image_bytes that
+ *                       g4s_rasterizer_layout(P, instance_capacity, width, height) reports
+ *   status_dev[4]     : DEVICE words written by the call: [0] num_rendered (the reference's count), [1] instances
+ *                       binned, [2] Gaussians that emit instances, [3] 1 if [1] > instance_capacity -- the frame
+ *                       is then incomplete (memory-safe, the surplus instances are dropped) and the caller must
+ *                       repeat it with a larger capacity.  Read them whenever convenient (e.g. once per N frames).
+ *   sh_rest           : NULL = `shs` is the packed [P,M,3] tensor; otherwise shs = [P,1,3], sh_rest = [P,M-1,3]
+ *
+ * Nothing is read back and no launch depends on a host-side count: the call returns as soon as its ~20 launches are
+ * queued.  The matching backward is g4s_rasterizer_backward[_split_sh] with R = instance_capacity (R only sizes the
+ * layout of the chunks and the workspace).  Returns G4S_OK or a negative G4S_ERR_*.
+ */
+int g4s_rasterizer_forward_presized(
+    char* geom_buffer, size_t geom_bytes, char* binning_buffer, size_t binning_bytes, char* image_buffer, size_t image_bytes,
+    int instance_capacity, uint32_t* status_dev,
+    int P, int D, int M,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* sh_rest, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy,
+    float* out_color, float* out_others, int* radii, int debug, void* stream);
 
 /* Near-plane visibility.  Replaces CudaRasterizer::Rasterizer::markVisible
  * (dsr/cuda_rasterizer/rasterizer.h:24-29, rasterizer_impl.cu:54-66,141-153).

@@ -554,3 +554,72 @@ def test_largest_tile_grid(hip_lib, oracle_mod):
     big["W"] = 4097
     with pytest.raises(RuntimeError, match="tiles"):
         run_hip(big)
+
+
+def test_presized_forward_never_blocks_the_host_and_matches(hip_lib):
+    """g4s_rasterizer_forward_presized (extension): caller-sized chunks, the counts stay on the device, no read-back.
+      * forward outputs, the blend state and all gradients (backward called with R = capacity) are bit-identical to the
+        reference-shaped entry point's, on packed and on split SH;
+      * the call returns while the GPU is still busy with work queued BEFORE it (the standard entry point cannot: it
+        waits for num_rendered);
+      * a capacity that is too small is reported through the device status word, without touching memory out of
+        bounds, and the same state object works again with a sufficient capacity."""
+    import time
+    import torch
+    from g4splat_amd.diff_surfel_rasterization import _C
+    inp = scene_inputs(P=60000, W=640, H=400, seed=17, D=3, bg=(0.2, 0.1, 0.3))
+    gr = cotangents(400, 640, seed=4)
+    base = run_hip(inp, gr)
+    R = int(base["R"])
+    a = base["args"]
+    t = lambda x: torch.as_tensor(x, device="cuda:0")
+
+    def presized(state, sh):
+        return _C.rasterize_gaussians_presized(state, a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"],
+                                               a["rotations"], 1.0, a["transMat"], a["view"], a["proj"], inp["tanfovx"],
+                                               inp["tanfovy"], inp["H"], inp["W"], sh, inp["D"], a["campos"], False, False)
+
+    def backward(fw, sh):
+        cap, color, others, radii, geom, binning, img = fw
+        return _C.rasterize_gaussians_backward(a["bg"], a["means3D"], radii, a["colors"], a["scales"], a["rotations"], 1.0,
+                                               a["transMat"], a["view"], a["proj"], inp["tanfovx"], inp["tanfovy"], t(gr[0]),
+                                               t(gr[1]), sh, inp["D"], a["campos"], geom, cap, binning, img, False)
+
+    state = _C.PresizedState(60000, 640, 400, int(R * 1.3) + 1000, "cuda:0")
+    for sh in (a["sh"], (a["sh"][:, :1].contiguous(), a["sh"][:, 1:].contiguous())):
+        fw = presized(state, sh)
+        st = state.status.tolist()
+        assert st[0] == R and st[3] == 0 and 0 < st[1] <= R and 0 < st[2] <= 60000, st
+        assert np.array_equal(fw[1].cpu().numpy(), base["color"]) and np.array_equal(fw[2].cpu().numpy(), base["others"])
+        assert np.array_equal(fw[3].cpu().numpy(), base["radii"])
+        g = backward(fw, sh)
+        names = ("means2D", "colors", "opacity", "means3D", "transMat", "sh", "scales", "rotations")
+        for n, x in zip(names, g):
+            if n == "sh" and isinstance(x, (tuple, list)):
+                x = torch.cat(list(x), dim=1)
+            assert np.array_equal(x.cpu().numpy(), base["grads"][n]), n
+    # --- the host does not wait: ~60 ms of GPU work is queued first
+    torch.cuda.synchronize()
+    spin = int(1.5e8)
+    torch.cuda._sleep(spin)
+    t0 = time.perf_counter()
+    fw = presized(state, a["sh"])
+    dt_presized = time.perf_counter() - t0
+    still_busy = not torch.cuda.current_stream().query()
+    torch.cuda.synchronize()
+    torch.cuda._sleep(spin)
+    t0 = time.perf_counter()
+    run_hip(inp)  # the reference-shaped forward: reads num_rendered back
+    dt_standard = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    assert still_busy and dt_presized < 0.02, (dt_presized, dt_standard)
+    assert dt_standard > 2 * dt_presized and dt_standard > 0.03, (dt_presized, dt_standard)
+    assert np.array_equal(fw[1].cpu().numpy(), base["color"])
+    # --- capacity too small: flagged on the device, nothing out of bounds, state reusable
+    small = _C.PresizedState(60000, 640, 400, max(1, state.status.tolist()[1] // 3), "cuda:0")
+    presized(small, a["sh"])
+    torch.cuda.synchronize()
+    st = small.status.tolist()
+    assert st[3] == 1 and st[0] == R, st
+    fw = presized(state, a["sh"])
+    assert state.status.tolist()[3] == 0 and np.array_equal(fw[1].cpu().numpy(), base["color"])

@@ -304,7 +304,7 @@ def test_scene_file_in_the_reference_layout_loads_and_renders(hip_lib):
     gpu.load_ply(path)  # default device: "cuda", like the reference (:484-491)
     assert gpu._xyz.is_cuda and gpu._xyz.shape == (200, 3) and gpu.use_mip_filter
     W, H = 160, 112
-    c = synthetic.look_at_camera((0.1, 0.05, -0.2), (0.6, 0.1, 0.9), (0, 1, 0), 1.3, W, H)  # inside the 2 x 1.5 x 1.2 m box
+    c = synthetic.look_at_camera((-0.8, 0.0, -0.4), (1.0, 0.1, 0.6), (0, 1, 0), 1.9, W, H)  # inside the 2 x 1.5 x 1.2 m box
     cam = SimpleNamespace(image_width=W, image_height=H, FoVx=c.FoVx, FoVy=c.FoVy, znear=0.01, zfar=100.0,
                           world_view_transform=torch.tensor(c.world_view_transform),
                           full_proj_transform=torch.tensor(c.full_proj_transform), camera_center=torch.tensor(c.camera_center))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel trace + stats, then PMC passes, of a short bench run.
-# Usage: tools/profile_gpu.sh <tag> [workload]
+# Usage: tools/profile_gpu.sh <tag> [workload] [provenance text, e.g. the commit the library was built from]
 set -u
 TAG=${1:-r01}
 WL=${2:-s3}
@@ -18,5 +18,5 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -- $BENCH > $OUT/pmc_$name.log 2>&1
 done
-python $REPO/tools/summarize_prof.py $OUT $OUT/traffic_$WL.json $WL > $OUT/summary.txt 2>&1
+python $REPO/tools/summarize_prof.py $OUT $OUT/traffic_$WL.json $WL "${3:-}" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -34,8 +34,7 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0)):
 # HBM traffic table for bench.py's roofline.traffic (profiles/traffic_<workload>.json)
 if len(sys.argv) >= 4:
     names = {"blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_fwd_kernel": "preprocess_fwd",
-             "fold_records_kernel": "fold_records", "preprocess_bwd_kernel": "preprocess_bwd", "emit_kernel": "emit",
-             "tile_ranges_kernel": "tile_ranges"}
+             "preprocess_bwd_kernel": "preprocess_bwd", "emit_kernel": "emit", "tile_ranges_kernel": "tile_ranges"}
     kern = {}
     for k in agg:
         key = names.get(k) or names.get(k.split("<")[0]) or ("tile_sort" if k.startswith("radix_scatter_kernel<unsigned long") else None)
@@ -46,6 +45,8 @@ if len(sys.argv) >= 4:
                 if c in agg[k]:
                     kern[key][c] = round(agg[k][c] / max(cnt[k][c], 1), 1)
     json.dump({"workload": sys.argv[3],
+               "provenance": (sys.argv[4] if len(sys.argv) >= 5 else "rocprofv3 --pmc passes (commit not recorded)") +
+                             " -- static: collected by tools/profile_gpu.sh, not measured in the bench run that quotes it",
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, mean per dispatch, KiB "
                          "(tools/profile_gpu.sh)",
                "correction": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE under-reports coalesced "
