@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--workload", default="s3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--presized", action="store_true",
+                    help="use g4s_rasterizer_forward_presized (no host read-back; extension) instead of the "
+                         "reference-shaped forward -- for the step-time comparison in DESIGN.md, not the default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,8 +130,13 @@ def main():
     # visibility), then ONE RCCL SUM all-reduce over xGMI of the rows visible on some rank (the whole bucket when
     # that is most of them).  Persistent buffers keep torch's caching allocator out of the timed region.
     grad_out = side = rmax = reducer = None
+    # G4S_BENCH_EXCHANGE=owner (default): OwnerReduce -- all_to_all of this rank's visible rows to index-shard owners +
+    # all_gather of the reduced shards (g4splat_amd/parallel.py); =allreduce: the visible-rows /
+    # dense SUM all-reduce of round 1.  If the owner exchange fails on this machine's RCCL during warm-up the bench
+    # falls back to the all-reduce and says so in config.parallelism.
+    exchange = os.environ.get("G4S_BENCH_EXCHANGE", "owner")
     if dist is not None:
-        from g4splat_amd.parallel import RowSparseAllReduce
+        from g4splat_amd.parallel import OwnerReduce, RowSparseAllReduce
         M = int(dev["sh"].shape[1])
         shapes = [("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 2)),
                   ("dL_drotations", (P, 4)), ("side", (P, 2))]
@@ -141,15 +149,26 @@ def main():
         side = views.pop("side")
         grad_out = views
         rmax = torch.zeros((P,), dtype=torch.int32, device=device)
-        reducer = RowSparseAllReduce(bucket, [v.view(P, -1) for v in grad_out.values()] + [side])
+        row_views = [v.view(P, -1) for v in grad_out.values()] + [side]
+        reducer = OwnerReduce(row_views) if exchange == "owner" else RowSparseAllReduce(bucket, row_views)
     exchanged_rows = []
 
+    pstate = None
+
     def step(i):
+        nonlocal pstate
         cam = dcams[(rank + i * world) % len(dcams)]
-        fw = _C.rasterize_gaussians(bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0,
-                                    empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"], H, W, dev["sh"],
-                                    D, cam["campos"], False, False)
+        if args.presized and pstate is not None:
+            fw = _C.rasterize_gaussians_presized(pstate, bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
+                                                 dev["rotations"], 1.0, empty, cam["view"], cam["proj"], cam["tanfovx"],
+                                                 cam["tanfovy"], H, W, dev["sh"], D, cam["campos"], False, False)
+        else:
+            fw = _C.rasterize_gaussians(bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0,
+                                        empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"], H, W, dev["sh"],
+                                        D, cam["campos"], False, False)
         R, color, others, radii, geom, binning, img = fw
+        if dist is not None and exchange == "owner":
+            reducer.begin(radii > 0)  # sizes travel to the host while the backward runs
         grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
                                                 1.0, empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"],
                                                 dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
@@ -160,12 +179,28 @@ def main():
             side[:, 1] = radii > 0
             rmax.copy_(radii)
             dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
-            reducer.reduce(rmax > 0)
-            exchanged_rows.append(reducer.last_rows)
+            if exchange == "owner":
+                reducer.finish()
+                exchanged_rows.append(reducer.last_rows_sent)
+            else:
+                reducer.reduce(rmax > 0)
+                exchanged_rows.append(reducer.last_rows)
         return R, radii
 
     # warm-up (also measures V and R per view outside the timed region)
     Vs, Rs = {}, {}
+    if dist is not None and exchange == "owner":
+        try:
+            step(0)
+            torch.cuda.synchronize()
+            ok = torch.ones(1, device=device)
+        except Exception as ex:  # e.g. an RCCL build without uneven all_to_all
+            print(f"[bench] owner exchange failed on rank {rank}: {ex}; falling back to all-reduce", file=sys.stderr)
+            ok = torch.zeros(1, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            exchange = "allreduce(fallback)"
+            reducer = RowSparseAllReduce(bucket, row_views)
     for i in range(max(args.warmup, 1)):
         R, radii = step(i)
         c = (rank + i * world) % len(dcams)
@@ -178,6 +213,11 @@ def main():
             Vs[c] = int((radii > 0).sum().item())
             Rs[c] = int(R)
 
+    if args.presized:  # capacity from the warm-up's instance counts, with head-room
+        pstate = _C.PresizedState(P, W, H, int(max(Rs.values()) * 1.25) + 4096, device)
+        step(0)
+        torch.cuda.synchronize()
+        assert pstate.status.tolist()[3] == 0
     timing = not args.no_kernel_timing
     lib.g4s_profile_reset()
     lib.g4s_profile_enable(1 if timing else 0)
@@ -290,8 +330,10 @@ def main():
                                f"{len(dcams)} views, 1 view/GPU/step", "P": P, "width": W, "height": H,
                    "sh_degree": D, "visible_per_view": round(units / args.steps / world),
                    "instances_per_view": round(inst / args.steps / world),
+                   "forward": "presized (no host read-back)" if args.presized else "reference-shaped",
                    "parallelism": f"view-dp{world}" + ((("+rccl" if backend == "nccl" else "+" + backend) +
-                                                                   "-visible-rows-allreduce") if world > 1 else ""),
+                                                                   ("-owner-reduce(all_to_all+all_gather)" if exchange == "owner"
+                                                                    else "-visible-rows-" + exchange)) if world > 1 else ""),
                    "exchanged_rows_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows
                                                else None)},
         "gaussians_total_per_s": P * args.steps * world / elapsed,

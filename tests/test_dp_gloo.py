@@ -62,7 +62,7 @@ def _step(model, views, vp):
         vp.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
 
 
-def _worker(rank, world, port, q, compact_below):
+def _worker(rank, world, port, q, compact_below, exchange="allreduce"):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,14 +72,15 @@ def _worker(rank, world, port, q, compact_below):
     model = _model(seed=rank)  # deliberately different replicas: the broadcast must fix that
     broadcast_parameters(model.parameters(), src=0)
     model.training_setup()
-    vp = ViewParallel(model.parameters(), compact_below=compact_below)
+    vp = ViewParallel(model.parameters(), compact_below=compact_below, exchange=exchange)
     views = _views(4)
     mine = shard_views(views, rank, world)
-    assert len(mine) == 2
+    assert len(mine) == 4 // world
     _step(model, mine, vp)
     stats = vp.all_reduce()
     flat = vp.bucket.flat.clone()
-    assert vp._reducer.last_rows == (150 if compact_below == 0.0 else int((stats["max_radii"] > 0).sum()))
+    if exchange == "allreduce":
+        assert vp._reducer.last_rows == (150 if compact_below == 0.0 else int((stats["max_radii"] > 0).sum()))
     model.optimizer.step()
     q.put((rank, flat.numpy(), stats["grad_norm_sum"].numpy(), stats["vis_count"].numpy(), stats["max_radii"].numpy(),
            torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy()))
@@ -87,17 +88,20 @@ def _worker(rank, world, port, q, compact_below):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("compact_below", [0.0, 1.1])  # dense exchange / visible-rows-only exchange
-def test_view_parallel_matches_single_process(compact_below):
+@pytest.mark.parametrize("compact_below,exchange,world", [(0.0, "allreduce", 2), (1.1, "allreduce", 2), (0.7, "owner", 2),
+                                                          (0.7, "owner", 4)])
+def test_view_parallel_matches_single_process(compact_below, exchange, world):
+    """dense all-reduce / visible-rows all-reduce / owner-reduce (2 and 4 ranks): the reduced bucket equals the sum of the
+    single-process gradients over the same views, the statistics follow the reference's semantics, replicas stay identical."""
     _setup_paths()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if compact_below else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact_below)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if compact_below else 0) + (13 if exchange == "owner" else 0) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, compact_below, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(2):
+    for _ in range(world):
         r = q.get(timeout=240)
         res[r[0]] = r[1:]
     for p in procs:
@@ -111,14 +115,16 @@ def test_view_parallel_matches_single_process(compact_below):
     vp = ViewParallel(model.parameters())
     _step(model, _views(4), vp)
     ref = vp.bucket.flat.numpy()
-    for r in (0, 1):
+    for r in range(world):
         flat, gsum, cnt, rad, params = res[r]
         assert np.abs(flat - ref).max() <= 1e-3 * np.abs(ref).max()
         np.testing.assert_allclose(gsum, vp.grad_norm_sum.numpy(), rtol=1e-4, atol=1e-7)
         np.testing.assert_array_equal(cnt, vp.vis_count.numpy())
         np.testing.assert_array_equal(rad, vp.max_radii.numpy())
     # replicas identical after the step (deterministic Adam on identical reduced gradients)
-    np.testing.assert_array_equal(res[0][4], res[1][4])
+    for r in range(1, world):
+        np.testing.assert_array_equal(res[0][4], res[r][4])
+        np.testing.assert_array_equal(res[0][0], res[r][0])  # and the reduced gradients are the same bits everywhere
     # 58 floats per Gaussian in the bucket
     assert ref.size == 150 * 58
 
@@ -182,3 +188,66 @@ def test_row_sparse_all_reduce_equals_dense():
         for frac, same, rows, n in res[r]:
             assert same, (r, frac)
             assert rows == (1000 if n > 700 else n), (frac, rows, n)
+
+
+def _owner_worker(rank, world, port, q):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from g4splat_amd.parallel import OwnerReduce
+    out = []
+    for P, frac, exact in ((1000, 0.3, True), (1003, 0.6, True), (257, 1.0, True), (64, 0.0, True), (1000, 0.3, False)):
+        vis = torch.rand(P, generator=torch.Generator().manual_seed(100 + rank + 17 * P)) < frac
+        flat = torch.zeros(P * 7)
+        rows = [flat[:3 * P].view(P, 3), flat[3 * P:].view(P, 4)]
+        g = torch.Generator().manual_seed(200 + rank)
+        # exact: small integers / 8 -> every partial sum is exactly representable, so ANY summation order gives the
+        # same bits and the comparison with the dense all-reduce is a bit-for-bit one at any world size
+        vals = (torch.randint(-64, 64, (P, 7), generator=g).float() / 8) if exact else torch.randn(P, 7, generator=g)
+        rows[0][vis] = vals[vis, :3]
+        rows[1][vis] = vals[vis, 3:]
+        dense = flat.clone()
+        dist.all_reduce(dense)
+        red = OwnerReduce(rows)
+        red.begin(vis)
+        red.finish()
+        if exact or world == 2:  # two addends commute: bit-identical for any values
+            ok = bool(torch.equal(flat, dense))
+        else:
+            ok = bool((flat - dense).abs().max() <= 1e-6 * dense.abs().max())
+        # determinism of the owner's summation order: a second exchange of the same inputs gives the same bits
+        flat2 = torch.zeros(P * 7)
+        rows2 = [flat2[:3 * P].view(P, 3), flat2[3 * P:].view(P, 4)]
+        rows2[0][vis] = vals[vis, :3]
+        rows2[1][vis] = vals[vis, 3:]
+        red2 = OwnerReduce(rows2)
+        red2.begin(vis)
+        red2.finish()
+        out.append((P, frac, exact, ok, bool(torch.equal(flat, flat2)), red.last_rows_sent, int(vis.sum())))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_owner_reduce_equals_dense_all_reduce(world):
+    """OwnerReduce (all_to_all of visible rows to index-shard owners, all_gather of the reduced shards) against the dense
+    SUM all-reduce: bit-identical on exactly representable values at 2 and 4 ranks (ragged last shard, empty and full
+    visibility included), bit-identical on arbitrary values at 2 ranks, equal to rounding at 4, and bit-reproducible."""
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for P, frac, exact, ok, same_again, sent, nvis in res[r]:
+            assert ok, (r, P, frac, exact)
+            assert same_again, (r, P, frac)
+            assert 0 <= sent <= nvis
