@@ -57,6 +57,9 @@ SIGNATURES = {
     "g4s_densify_stats": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "g4s_activations_forward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "g4s_activations_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "g4s_compact_workspace": (c_sz, [c_i]),
+    "g4s_compact_scan": (c_i, [c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "g4s_compact_gather": (c_i, [c_i, c_p, c_p, c_i, c_p, c_p, c_p, ctypes.c_longlong, c_p]),
     # include/g4s_losses.h
     "g4s_photometric_workspace": (c_sz, [c_i, c_i]),
     "g4s_photometric_loss": (c_i, [c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_sz, c_p]),

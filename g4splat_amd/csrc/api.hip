@@ -704,6 +704,44 @@ extern "C" int g4s_adam_step(int nseg, float* const* params, const float* const*
     return G4S_OK;
 }
 
+// ---- stream compaction of Gaussian rows (include/g4s_optim.h) ------------------------------------
+extern "C" int g4s_compact_scan_launch_internal(int P, const uint8_t* keep, int* out_count, char* workspace, hipStream_t s);
+extern "C" int g4s_compact_gather_launch_internal(int P, const uint8_t* keep, const char* workspace, int nseg,
+                                                  const float* const* src, float* const* dst, const int* widths,
+                                                  long long dst_row0, hipStream_t s);
+
+extern "C" int g4s_compact_scan(int P, const unsigned char* keep, int* out_count, char* workspace, size_t workspace_bytes,
+                                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P must not be negative");
+    if (!out_count || !workspace || (P > 0 && !keep)) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    if (workspace_bytes < g4s_compact_workspace(P)) return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");
+    if (P == 0) {
+        if (hipMemsetAsync(out_count, 0, sizeof(int), stream) != hipSuccess) return fail(G4S_ERR_HIP, "memset failed");
+        return G4S_OK;
+    }
+    g4s_compact_scan_launch_internal(P, keep, out_count, workspace, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(G4S_ERR_HIP, "compact_scan launch: %s", hipGetErrorString(e));
+    return G4S_OK;
+}
+
+extern "C" int g4s_compact_gather(int P, const unsigned char* keep, const char* workspace, int nseg, const float* const* src,
+                                  float* const* dst, const int* widths, long long dst_row0, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    t_err[0] = 0;
+    if (P < 0 || nseg < 0 || dst_row0 < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "P, nseg, dst_row0 must not be negative");
+    if (P == 0 || nseg == 0) return G4S_OK;
+    if (!keep || !workspace || !src || !dst || !widths) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
+    for (int i = 0; i < nseg; i++)
+        if (!src[i] || !dst[i] || widths[i] <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "tensor %d: NULL pointer or width <= 0", i);
+    g4s_compact_gather_launch_internal(P, keep, workspace, nseg, src, dst, widths, dst_row0, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(G4S_ERR_HIP, "compact_gather launch: %s", hipGetErrorString(e));
+    return G4S_OK;
+}
+
 // ---- packed rows for the visible-rows gradient exchange ------------------------------------------
 extern "C" void g4s_densify_stats_launch_internal(int P, const float* grad, const unsigned char* filter, const int* radii,
                                                   float* accum, float* denom, float* max_radii, hipStream_t s);

@@ -2,8 +2,10 @@
 2dgs/scene/gaussian_model.py:436-651 -- reset_opacity, prune_points, densify_and_clone, densify_and_split,
 densify_and_prune, compute_mip_filter (:388-434) -- with the same selection rules, the same new-point
 construction and the same optimiser-state surgery (moments of kept rows survive, new rows start at zero), written
-once around a single row-edit primitive instead of three copies of the group loop.  Device-agnostic torch (these
-run every 100 iterations; the per-iteration work is in the HIP kernels); works with torch.optim.Adam and
+once around a single row-edit primitive instead of three copies of the group loop.  On the HIP device the row
+filtering is stream compaction in the library (optim.compact_rows -> g4s_compact_scan / g4s_compact_gather: wave
+ballot + prefix sum, the mask scanned once for all eighteen tensors); host tensors take torch indexing, which is
+what tests/test_densify.py replays against the reference's own GaussianModel.  Works with torch.optim.Adam and
 optim.FusedAdam alike because both keep `state[p] = {step, exp_avg, exp_avg_sq}`.
 
 Mixed into GaussianModel (gaussian_model.py imports DensifyMixin)."""
@@ -27,37 +29,62 @@ class DensifyMixin:
     percent_dense = 0.01  # arguments/__init__.py: OptimizationParams.percent_dense
 
     # ---- the one primitive: keep a subset of rows and / or append rows, in the parameters AND in the optimiser ----
-    def _edit_rows(self, keep=None, append=None, zero_moments=False):
-        """keep: bool[P] or None; append: dict group-name -> new rows or None.  Returns nothing; rebinds the six
-        parameters (gaussian_model.py:495-560: replace_tensor_to_optimizer / _prune_optimizer /
-        cat_tensors_to_optimizer)."""
-        # one mask -> index conversion (and one host sync) for all eighteen tensors instead of one per tensor
-        keep_idx = torch.nonzero(keep).squeeze(1) if keep is not None else None
-        for group in self.optimizer.param_groups:
-            assert len(group["params"]) == 1
-            old = group["params"][0]
-            name = group["name"]
-            if name not in _FIELDS:
-                continue
-            state = self.optimizer.state.pop(old, None)
-            data = old.detach()
-            if keep is not None:
-                data = data.index_select(0, keep_idx)
-            extra = append[name] if append is not None else None
+    def _edit_rows(self, keep=None, append=None, zero_moments=False, also=()):
+        """keep: bool[P] or None; append: dict group-name -> new rows or None; also: further [P, ...] tensors to filter
+        with `keep` (the densification statistics).  Rebinds the six parameters (gaussian_model.py:495-560:
+        replace_tensor_to_optimizer / _prune_optimizer / cat_tensors_to_optimizer) and returns the filtered `also`.
+
+        HIP tensors: `keep` is scanned once and all eighteen tensors (+ `also`) are compacted against that scan
+        (optim.compact_rows: wave ballot + prefix sum, three gather launches); host tensors take torch indexing."""
+        groups = [g for g in self.optimizer.param_groups if g["name"] in _FIELDS]
+        for g in groups:
+            assert len(g["params"]) == 1
+        olds = [g["params"][0] for g in groups]
+        states = [self.optimizer.state.pop(o, None) for o in olds]
+        has_state = [st is not None and len(st) > 0 for st in states]
+        extras = [append[g["name"]].detach() if append is not None else None for g in groups]
+        # every tensor that has to be filtered, in one list
+        work = [o.detach() for o in olds]
+        for st, ok in zip(states, has_state):
+            if ok:
+                work += [st["exp_avg"], st["exp_avg_sq"]]
+        n_also = len(also)
+        work += [a.float() if a.dtype != torch.float32 else a for a in also]
+        if keep is None:
+            filtered = work
+        elif work[0].is_cuda:
+            from .optim import compact_rows
+            _n, filtered = compact_rows(keep, work)
+        else:
+            keep_idx = torch.nonzero(keep).squeeze(1)  # one mask -> index conversion for all tensors
+            filtered = [t.index_select(0, keep_idx) for t in work]
+        it = iter(filtered)
+        datas = [next(it) for _ in olds]
+        moments = [(next(it), next(it)) if ok else None for ok in has_state]
+        also_out = [next(it) for _ in range(n_also)]
+        for g, old, st, ok, data, mom, extra in zip(groups, olds, states, has_state, datas, moments, extras):
             if extra is not None:
-                data = torch.cat((data, extra.detach()), dim=0)
+                data = torch.cat((data, extra), dim=0)
             new = nn.Parameter(data.contiguous().requires_grad_(True))
-            if state is not None and len(state) > 0:
-                for key in ("exp_avg", "exp_avg_sq"):
-                    m = state[key]
-                    if keep is not None:
-                        m = m.index_select(0, keep_idx)
+            if ok:
+                for key, m in zip(("exp_avg", "exp_avg_sq"), mom):
                     if extra is not None:
                         m = torch.cat((m, torch.zeros_like(extra)), dim=0)
-                    state[key] = torch.zeros_like(new) if zero_moments else m.contiguous()
-                self.optimizer.state[new] = state
-            group["params"][0] = new
-            setattr(self, _FIELDS[name], new)
+                    st[key] = torch.zeros_like(new) if zero_moments else m.contiguous()
+                self.optimizer.state[new] = st
+            g["params"][0] = new
+            setattr(self, _FIELDS[g["name"]], new)
+        return also_out
+
+    @staticmethod
+    def _pick(sel, tensors):
+        """[t[sel] for t in tensors]: one mask scan + one gather launch on the HIP device, torch indexing on the host."""
+        ts = [t.detach() for t in tensors]
+        if ts[0].is_cuda:
+            from .optim import compact_rows
+            return compact_rows(sel, ts)[1]
+        i = torch.nonzero(sel).squeeze(1)
+        return [t.index_select(0, i) for t in ts]
 
     # ---- reference-named entry points --------------------------------------------------------------------------
     def replace_tensor_to_optimizer(self, tensor, name):
@@ -94,13 +121,14 @@ class DensifyMixin:
     def prune_points(self, mask):
         """:527-541: drop the rows where `mask` is True, everywhere (parameters, moments, statistics)."""
         keep = ~mask
-        self._edit_rows(keep=keep)
-        keep_idx = torch.nonzero(keep).squeeze(1)
-        self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, keep_idx)
-        self.denom = self.denom.index_select(0, keep_idx)
-        self.max_radii2D = self.max_radii2D.index_select(0, keep_idx)
-        if self.mip_filter is not None and self.mip_filter.shape[0] == keep.shape[0]:
-            self.mip_filter = self.mip_filter.index_select(0, keep_idx)
+        stats = [self.xyz_gradient_accum, self.denom, self.max_radii2D]
+        has_mip = self.mip_filter is not None and self.mip_filter.shape[0] == keep.shape[0]
+        if has_mip:
+            stats.append(self.mip_filter)
+        out = self._edit_rows(keep=keep, also=stats)
+        self.xyz_gradient_accum, self.denom, self.max_radii2D = out[0], out[1], out[2]
+        if has_mip:
+            self.mip_filter = out[3]
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation):
         """:562-581: append rows; the densification statistics restart from zero for everybody."""
@@ -115,10 +143,8 @@ class DensifyMixin:
         """:612-626: small Gaussians with a large screen-space gradient are duplicated in place."""
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
               (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
-        i = torch.nonzero(sel).squeeze(1)
-        pick = lambda t: t.index_select(0, i)
-        self.densification_postfix(pick(self._xyz), pick(self._features_dc), pick(self._features_rest), pick(self._opacity),
-                                   pick(self._scaling), pick(self._rotation))
+        self.densification_postfix(*self._pick(sel, [self._xyz, self._features_dc, self._features_rest, self._opacity,
+                                                     self._scaling, self._rotation]))
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
         """:583-610: large Gaussians with a large gradient are replaced by N children sampled inside them (in the
@@ -127,17 +153,17 @@ class DensifyMixin:
         padded = torch.zeros((P,), device=self._xyz.device)
         padded[:grads.shape[0]] = grads.squeeze(-1) if grads.ndim > 1 else grads
         sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
-        i = torch.nonzero(sel).squeeze(1)
-        pick = lambda t: t.index_select(0, i)
-        s = pick(self.get_scaling).repeat(N, 1)
+        p_scal, p_rot, p_xyz, p_dc, p_rest, p_opa = self._pick(sel, [self.get_scaling, self._rotation, self._xyz,
+                                                                     self._features_dc, self._features_rest, self._opacity])
+        s = p_scal.repeat(N, 1)
         stds = torch.cat([s, torch.zeros_like(s[:, :1])], dim=-1)
         samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
-        R = build_rotation(pick(self._rotation)).repeat(N, 1, 1)
-        new_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + pick(self._xyz).repeat(N, 1)
+        R = build_rotation(p_rot).repeat(N, 1, 1)
+        new_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + p_xyz.repeat(N, 1)
         new_scaling = torch.log(s / (0.8 * N))
-        self.densification_postfix(new_xyz, pick(self._features_dc).repeat(N, 1, 1), pick(self._features_rest).repeat(N, 1, 1),
-                                   pick(self._opacity).repeat(N, 1), new_scaling, pick(self._rotation).repeat(N, 1))
-        gone = torch.cat((sel, torch.zeros(N * int(i.numel()), dtype=torch.bool, device=sel.device)))
+        self.densification_postfix(new_xyz, p_dc.repeat(N, 1, 1), p_rest.repeat(N, 1, 1), p_opa.repeat(N, 1), new_scaling,
+                                   p_rot.repeat(N, 1))
+        gone = torch.cat((sel, torch.zeros(N * int(p_xyz.shape[0]), dtype=torch.bool, device=sel.device)))
         self.prune_points(gone)
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):

@@ -164,3 +164,47 @@ def fused_activations(scaling, rotation, opacity):
             or any(t.dtype != torch.float32 for t in (scaling, rotation, opacity))):
         raise RuntimeError("fused_activations: expected float32 scaling [P,2], rotation [P,4], opacity [P,1]")
     return _Activations.apply(scaling, rotation, opacity)
+
+
+@torch.no_grad()
+def compact_rows(keep, tensors, extra_rows=0):
+    """Stream compaction on the HIP device (include/g4s_optim.h, g4s_compact_scan / g4s_compact_gather): the rows
+    `keep` marks (bool [P]) of every tensor in `tensors` (float32, contiguous, [P, ...]), in index order -- what
+    `t[keep]` returns for each of them, with ONE scan of the mask and one gather launch per eight tensors instead of a
+    mask -> index conversion and an indexing kernel per tensor.  Returns (n_kept, new tensors); each new tensor has
+    n_kept + extra_rows rows (the tail is uninitialised: the caller appends there).  One host read-back (n_kept: the
+    new tensors' shapes need it), like the reference's mask indexing."""
+    P = int(keep.shape[0])
+    dev = keep.device
+    if not keep.is_cuda:
+        raise RuntimeError("compact_rows: HIP tensors only")
+    if keep.dtype != torch.bool or keep.ndim != 1:
+        raise RuntimeError("compact_rows: keep must be bool [P]")
+    src = []
+    for t in tensors:
+        if t.dtype != torch.float32 or t.shape[0] != P or t.device != dev:
+            raise RuntimeError("compact_rows: tensors must be float32 [P, ...] on the mask's device")
+        src.append(t.detach().contiguous())
+    lib = _lib.load()
+    keep_c = keep.contiguous()
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        nws = lib.g4s_compact_workspace(P)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.g4s_compact_scan(P, ctypes.c_void_p(keep_c.data_ptr()), ctypes.c_void_p(count.data_ptr()),
+                                  ctypes.c_void_p(ws.data_ptr()), nws, stream)
+        if rc != 0:
+            raise RuntimeError(f"g4s_compact_scan failed ({rc}): {_lib.last_error()}")
+        n = int(count.item())
+        out = [torch.empty((n + int(extra_rows),) + tuple(t.shape[1:]), dtype=torch.float32, device=dev) for t in src]
+        k = len(src)
+        if k and P and n > 0:  # (n == 0: nothing to copy, and empty outputs have no address)
+            widths = [int(t[0].numel()) if t.ndim > 1 else 1 for t in src]
+            rc = lib.g4s_compact_gather(P, ctypes.c_void_p(keep_c.data_ptr()), ctypes.c_void_p(ws.data_ptr()), k,
+                                        (ctypes.c_void_p * k)(*[t.data_ptr() for t in src]),
+                                        (ctypes.c_void_p * k)(*[t.data_ptr() for t in out]), (ctypes.c_int * k)(*widths), 0,
+                                        stream)
+            if rc != 0:
+                raise RuntimeError(f"g4s_compact_gather failed ({rc}): {_lib.last_error()}")
+    return n, out

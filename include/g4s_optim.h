@@ -56,6 +56,23 @@ int g4s_activations_backward(int P, const float* scales, const float* rotation_r
                              const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
                              float* dL_dscaling_raw, float* dL_drotation_raw, float* dL_dopacity_raw, void* stream);
 
+/*
+ * Stream compaction of Gaussian rows: the device side of prune_points / densify_and_clone / densify_and_split
+ * (2d-gaussian-splatting/scene/gaussian_model.py:510-541, 583-626), which the reference expresses as one boolean-mask
+ * indexing per tensor (six parameters, twelve Adam moments, three statistics).
+ *
+ *   g4s_compact_scan    scans `keep` (one byte per row, a torch bool tensor) ONCE: wave ballot + popcount per 256 rows,
+ *                       a single-block scan of the block counts; the number of kept rows goes to *out_count (device int).
+ *                       `workspace` (>= g4s_compact_workspace(P) bytes) holds the scan for the gathers that follow.
+ *   g4s_compact_gather  copies the kept rows of `nseg` row-major float tensors src[s] = [P, widths[s]] to
+ *                       dst[s] + dst_row0 * widths[s], in index order (stable, like mask indexing), eight tensors per
+ *                       launch.  src / dst / widths are HOST arrays.  dst[s] must hold dst_row0 + count rows.
+ */
+size_t g4s_compact_workspace(int P);
+int g4s_compact_scan(int P, const unsigned char* keep, int* out_count, char* workspace, size_t workspace_bytes, void* stream);
+int g4s_compact_gather(int P, const unsigned char* keep, const char* workspace, int nseg, const float* const* src,
+                       float* const* dst, const int* widths, long long dst_row0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,93 @@ def test_densify_on_gpu_then_keep_training(hip_lib):
     assert float(model.get_opacity.detach().max()) <= 0.0100001
     assert np.isfinite(iterate(6))
     assert float(model.optimizer.state[model._xyz]["step"]) == 12
+
+
+def test_config3_densify_and_prune_schedule_at_metric_size(hip_lib, capsys):
+    """BASELINE config 3: 1.5 M surfels, 1600x1200, the densify + prune loop -- the schedule of
+    arguments/__init__.py:90-94 (densify every 100 iterations between 500 and 15 000 of 30 000, opacity reset every
+    3 000, SH degree up every 1 000) compressed 100:1 to 300 iterations: densify_and_prune at 50 / 100 / 150, one
+    opacity reset at 125, SH degree raised every 10 iterations.  Product path only (render(), fused loss and
+    regularisers, FusedAdam, fused statistics, HIP compaction in prune / clone / split): a displaced, recoloured copy
+    of the room scene is re-fitted to renders of the original from eight views.  Checks: the loss falls, every
+    parameter and moment stays finite, the set really is edited (and the optimiser state follows it), PSNR improves."""
+    import time
+    from g4splat_amd.losses import geometry_regularizers
+    dev = torch.device("cuda:0")
+    P, W_, H_ = 1_500_000, 1600, 1200
+    truth_scene = synthetic.scene_room(P, seed=0)
+    cams_np = synthetic.room_cameras(8, W_, H_, fovx_deg=90.0)
+    cams = [SimpleNamespace(image_width=W_, image_height=H_, FoVx=c.FoVx, FoVy=c.FoVy, znear=0.01, zfar=100.0,
+                            world_view_transform=torch.tensor(c.world_view_transform, device=dev),
+                            full_proj_transform=torch.tensor(c.full_proj_transform, device=dev),
+                            camera_center=torch.tensor(c.camera_center, device=dev)) for c in cams_np]
+
+    def model_from(scene, jitter):
+        rng = np.random.default_rng(5)
+        m = GaussianModel(3)
+        xyz = scene.means3D + (rng.normal(0, 0.004, scene.means3D.shape).astype(np.float32) if jitter else 0)
+        cols = np.clip(scene.shs[:, 0, :] * 0.28209479177387814 + 0.5, 0, 1)
+        if jitter:
+            cols = 0.5 * cols + 0.25
+        m.create_from_parameters(torch.tensor(xyz, device=dev), torch.tensor(scene.scales, device=dev),
+                                 torch.tensor(scene.rotations, device=dev), torch.tensor(cols.astype(np.float32), device=dev), 1.0)
+        with torch.no_grad():
+            op = np.clip(scene.opacities, 1e-4, 1 - 1e-4)
+            m._opacity.copy_(torch.tensor(np.log(op / (1 - op)), device=dev))
+            if not jitter:
+                m._features_rest.copy_(torch.tensor(scene.shs[:, 1:, :], device=dev))
+        return m
+
+    pipe = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+    truth = model_from(truth_scene, False)
+    truth.active_sh_degree = 3
+    with torch.no_grad():
+        targets = [render(c, truth, pipe, bg)["render"].clone() for c in cams]
+    del truth
+    model = model_from(truth_scene, True)
+    model.training_setup()
+    psnr = lambda a, b: float(10 * torch.log10(1.0 / ((a - b) ** 2).mean()))
+    with torch.no_grad():
+        psnr0 = np.mean([psnr(render(c, model, pipe, bg)["render"], t) for c, t in zip(cams, targets)])
+    losses, sizes = [], [int(model.get_xyz.shape[0])]
+    torch.manual_seed(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, 301):
+        model.update_learning_rate(it * 100)
+        if it % 10 == 0:
+            model.oneupSHdegree()
+        cam, gt = cams[it % 8], targets[it % 8]
+        out = render(cam, model, pipe, bg)
+        loss, _l1, _s = photometric_loss(out["render"], gt, 0.2)
+        nrm, dist_l = geometry_regularizers(out["rend_normal"], out["surf_normal"], out["rend_dist"])
+        total = loss + (0.05 * nrm if it > 70 else 0.0) + (100.0 * dist_l if it > 30 else 0.0)  # lambda_normal / lambda_dist
+        total.backward()
+        with torch.no_grad():
+            if it < 150:
+                model.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
+                if it in (50, 100):
+                    model.densify_and_prune(0.0002, 0.05, 6.0, 20 if it > 30 else None)
+                    sizes.append(int(model.get_xyz.shape[0]))
+                if it == 125:
+                    model.reset_opacity()
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=True)
+        if it % 10 == 0:
+            losses.append(float(total.detach()))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = int(model.get_xyz.shape[0])
+    for p in model.parameters():
+        assert p.shape[0] == n and bool(torch.isfinite(p).all())
+        st = model.optimizer.state[p]
+        assert st["exp_avg"].shape == p.shape and bool(torch.isfinite(st["exp_avg"]).all()) and bool(torch.isfinite(st["exp_avg_sq"]).all())
+    assert model.xyz_gradient_accum.shape[0] == n and model.max_radii2D.shape[0] == n
+    assert len(set(sizes)) > 1, sizes  # the set was edited
+    with torch.no_grad():
+        psnr1 = np.mean([psnr(render(c, model, pipe, bg)["render"], t) for c, t in zip(cams, targets)])
+    with capsys.disabled():
+        print(f"\nC3 schedule at 1.5 M: sizes {sizes} -> {n}, loss {losses[0]:.4f} -> {losses[-1]:.4f}, PSNR {psnr0:.2f} -> {psnr1:.2f} dB, "
+              f"{dt / 300 * 1e3:.2f} ms per iteration incl. densification")
+    assert psnr1 > psnr0 + 1.0, (psnr0, psnr1)

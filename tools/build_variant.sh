@@ -9,7 +9,7 @@ out="${@: -1}"
 objs=""
 declare -A repl
 for a in "${@:1:$#-1}"; do repl[${a%%=*}]=${a#*=}; done
-for u in api preprocess binning blend knn maps loss; do
+for u in api preprocess binning blend knn maps loss densify; do
   if [ -n "${repl[$u]:-}" ]; then
     cp "${repl[$u]}" $CS/_variant_$u.hip
     /opt/rocm/bin/hipcc $FLAGS -c $CS/_variant_$u.hip -o /tmp/_variant_$u.o
