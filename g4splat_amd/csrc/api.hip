@@ -370,7 +370,7 @@ static int rasterizer_forward_impl(
         if (R_binned > 0) {
             { ProfScope ps(PF_EMIT, stream);  // (also clears the contribution masks qhit[0, R_binned))
               launch_emit(V_emit, (uint32_t)R_binned, tiles_x, tiles_y, gidx_sorted, block_offs, nblocks_v, rank_local,
-                          radii, rec, ent_a, qhit_ptr, stream, d_counts); }
+                          radii, rec, ent_a, qhit_ptr, (uint8_t*)(bin + BL.rec_flag), stream, d_counts); }
             CHECK_LAUNCH("emit");
             const int tile_bits = tile_sort_bits(tiles);  // rasterizer_impl.cu:301
             int c2;
@@ -456,9 +456,9 @@ extern "C" int g4s_rasterizer_forward_presized(
 }
 
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
-    // gradient records | one validity byte per record | deep-tile counter + list
+    // gradient records | deep-tile counter + list   (the records' validity bytes live in the forward's binning chunk)
     (void)P;
-    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + align_up((size_t)(R > 0 ? R : 1)) + 256 + 65536 * 4 + 256;
+    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + 256 + 65536 * 4 + 256;
 }
 
 static int rasterizer_backward_impl(
@@ -500,13 +500,16 @@ static int rasterizer_backward_impl(
     // its gather, K8b writes the others: no memset of the 192 B x P tensor)
     // gradient records: only instances that receive a contribution are written by the blend backward; instead of
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
-    uint8_t* rec_flag = (uint8_t*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4);
-    // the deep-tile counter sits right behind the validity bytes so that one memset clears both
-    uint32_t* hot_count = (uint32_t*)(rec_flag + align_up((size_t)(R > 0 ? R : 1)));
+    // the deep-tile counter + list sit behind the records; the counter is cleared by the tile-order kernel below
+    uint32_t* hot_count = (uint32_t*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));
     uint32_t* hot_list = hot_count + 64;
-    if (R > 0) HIP_TRY(hipMemsetAsync(rec_flag, 0, align_up((size_t)R) + 256, stream));
+    // One validity byte per record slot says which records the blend backward wrote; the bytes live in the binning chunk
+    // and were cleared by the forward (emit).  A second backward over the same forward state finds them set -- to the
+    // values it is going to write again (which records are written depends on the forward's state only).
+    uint8_t* rec_flag = nullptr;
     if (R > 0) {
         char* bin = align_ptr(binning_buffer);
+        rec_flag = (uint8_t*)(bin + BL.rec_flag);
         const int tile_bits = tile_sort_bits(tiles);
         const int passes = (tile_bits + 7) / 8;
         BlendBwdArgs bb{};
@@ -514,7 +517,7 @@ static int rasterizer_backward_impl(
         bb.ranges = (const uint32_t*)(img + IL.ranges);
         // backward order: most blended (entry, quadrant) pairs first -- the forward counted them per tile
         uint32_t* tile_order_bwd = (uint32_t*)(img + IL.tile_order_bwd);
-        launch_tile_order(tiles, (const uint32_t*)(img + IL.tile_depth), tile_order_bwd, stream);
+        launch_tile_order(tiles, (const uint32_t*)(img + IL.tile_depth), tile_order_bwd, stream, hot_count);
         bb.tile_order = getenv("G4S_BWD_FWD_ORDER") ? (const uint32_t*)(img + IL.tile_order) : tile_order_bwd;
         bb.entries = (const uint64_t*)(bin + ((passes & 1) ? BL.ent_b : BL.ent_a));
         bb.rec = rec; bb.bg = background;

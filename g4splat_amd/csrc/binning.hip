@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tile
                                                    const uint32_t* __restrict__ rank_local,
                                                    const int* __restrict__ radii, const float* __restrict__ rec,
                                                    uint64_t* __restrict__ entries, uint8_t* __restrict__ qhit,
+                                                   uint8_t* __restrict__ rec_flag,
                                                    const uint32_t* __restrict__ d_counts) {
     __shared__ uint32_t s_off[EMIT_SLOTS + 4];  // first slot of the staged ranks (ascending), then a sentinel
     __shared__ uint32_t s_idx[EMIT_SLOTS + 4];
@@ -340,9 +341,14 @@ __global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tile
     const uint32_t w1 = min(w0 + (uint32_t)EMIT_SLOTS, R_b);
     // contribution masks of this window (bytes [w0, w1)); w0 is a multiple of 1024, the array base 256-B aligned
     {
+        // (and the validity bytes of the backward's gradient-record slots [w0, w1): the slot space has the same size)
         const uint32_t o = w0 + 4u * (uint32_t)t;
-        if (o + 4u <= w1) *reinterpret_cast<uint32_t*>(qhit + o) = 0u;
-        else for (uint32_t i = o; i < w1; i++) qhit[i] = 0;
+        if (o + 4u <= w1) {
+            *reinterpret_cast<uint32_t*>(qhit + o) = 0u;
+            *reinterpret_cast<uint32_t*>(rec_flag + o) = 0u;
+        } else {
+            for (uint32_t i = o; i < w1; i++) { qhit[i] = 0; rec_flag[i] = 0; }
+        }
     }
     if (t == 0) s_nr = 0;
     // the 256-rank group that holds slot w0: last g with block_offs[g] <= w0 (block_offs[0] == 0)
@@ -444,10 +450,10 @@ void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs
 
 void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
                  int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
-                 uint8_t* qhit, hipStream_t s, const uint32_t* d_counts) {
+                 uint8_t* qhit, uint8_t* rec_flag, hipStream_t s, const uint32_t* d_counts) {
     if (R_b == 0) return;  // (d_counts != NULL: R_b is the capacity the grid is sized for)
     hipLaunchKernelGGL(emit_kernel, dim3((R_b + EMIT_SLOTS - 1) / EMIT_SLOTS), dim3(256), 0, s, V, R_b, tiles_x, tiles_y,
-                       gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit, d_counts);
+                       gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit, rec_flag, d_counts);
 }
 
 // rasterizer_impl.cu:116-138 on the packed entries (ranges pre-zeroed by the caller, :311)
@@ -479,10 +485,11 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int R, const uint64_t*
 // and per-group ordering costs more balance than the L2 locality returns.)
 constexpr int ORDER_BUCKETS = 2048;
 __global__ void __launch_bounds__(1024) tile_order_kernel(int tiles, const uint32_t* __restrict__ ranges,
-                                                          uint32_t* __restrict__ order) {
+                                                          uint32_t* __restrict__ order, uint32_t* __restrict__ zero_word) {
     __shared__ uint32_t hist[ORDER_BUCKETS];
     __shared__ uint32_t wsum[16];
     const int t = (int)threadIdx.x;
+    if (t == 0 && zero_word != nullptr) *zero_word = 0u;  // (the backward's deep-tile counter: saves a memset launch)
     for (int i = t; i < ORDER_BUCKETS; i += 1024) hist[i] = 0;
     __syncthreads();
     auto bucket = [](uint32_t n) {  // descending: long lists -> small bucket index
@@ -505,8 +512,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int tiles, const uint3
     __syncthreads();
     for (int i = t; i < tiles; i += 1024) order[atomicAdd(&hist[bucket(ranges[2 * i + 1] - ranges[2 * i])], 1u)] = (uint32_t)i;
 }
-void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, ranges, tile_order);
+void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s, uint32_t* zero_word) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, tiles, ranges, tile_order, zero_word);
 }
 
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s, const uint32_t* d_n) {

@@ -53,7 +53,7 @@ struct GeomLayout {
     int nblocks;   // 256-wide blocks over P
 };
 struct BinLayout {
-    size_t ent_a, ent_b, hist, bin_total, qhit, bytes;
+    size_t ent_a, ent_b, hist, bin_total, qhit, rec_flag, bytes;
 };
 struct ImgLayout {
     size_t ranges, final_T, n_contrib, tile_order, tile_depth, tile_order_bwd, bytes;
@@ -95,6 +95,9 @@ inline BinLayout bin_layout(size_t R) {
     L.hist = take((size_t)256 * (sort_blocks(R, SORT_ITEMS_U64) + 1) * 4);
     L.bin_total = take(256 * 4);
     L.qhit = take((R ? R : 1));
+    // one validity byte per gradient-record slot of the backward (cleared by emit together with qhit): bit 0 = terms
+    // 0..15 written, bit 1 = the low-pass terms 16..17 written
+    L.rec_flag = take((R ? R : 1));
     L.bytes = o + 256;
     return L;
 }
@@ -159,13 +162,13 @@ void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs
 void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec,
                               const uint32_t* depth_keys, const uint32_t* vis_block_offs, uint32_t* keys_out,
                               uint32_t* idx_out, int nblocks, hipStream_t s);
-// Instances in depth order, R_b of them; also clears qhit[0, R_b).
+// Instances in depth order, R_b of them; also clears qhit[0, R_b) and rec_flag[0, R_b).
 void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
                  int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
-                 uint8_t* qhit, hipStream_t s, const uint32_t* d_counts = nullptr);
+                 uint8_t* qhit, uint8_t* rec_flag, hipStream_t s, const uint32_t* d_counts = nullptr);
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s, const uint32_t* d_n = nullptr);
 // Longest-list-first processing order of the tiles (work balance of the blend kernels).
-void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s);
+void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s, uint32_t* zero_word = nullptr);
 
 struct BlendFwdArgs {
     int W, H, tiles_x, tiles_y;
@@ -198,7 +201,7 @@ struct BlendBwdArgs {
     const float* dL_dpix;
     const float* dL_depths;
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
-    uint8_t* rec_flag; // R bytes, pre-cleared: bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
+    uint8_t* rec_flag; // R bytes (binning chunk, cleared by the forward's emit): bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
     int no_fastpath;   // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
     // deep tiles (more than hot_threshold live list positions) are left to blend_bwd_hot_kernel: the one-wave
     // kernel appends them to hot_list (hot_count pre-cleared), the four-wave kernel runs behind it
