@@ -719,15 +719,24 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
             for (uint32_t k0 = 0; k0 < cmax; k0 += 16) {
                 float4 x[U][4];
                 uint8_t f[U][4];
+                // the validity bytes first, then only the records the blend backward wrote (about half of the slots
+                // belong to instances that no pixel blended): the kernel is bound by HBM traffic, and the 80-byte
+                // records are most of what it reads
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t k = k0 + 4 * i + kk;
+                        f[u][i] = k < cn[u] ? a.rec_flag[of[u] + k] : (uint8_t)0;
+                    }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const float4* base4 = reinterpret_cast<const float4*>(a.grad_inst + (size_t)of[u] * GRAD_STRIDE);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t k = k0 + 4 * i + kk;
-                        const uint32_t kc = k < cn[u] ? k : 0u;
-                        x[u][i] = base4[(size_t)kc * (GRAD_STRIDE / 4) + c];
-                        f[u][i] = a.rec_flag[of[u] + kc];
+                        x[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (f[u][i] & 1) x[u][i] = base4[(size_t)k * (GRAD_STRIDE / 4) + c];
                     }
                 }
                 // records the blend backward never wrote hold garbage (possibly NaN): select, do not multiply
@@ -736,11 +745,10 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const uint32_t k = k0 + 4 * i + kk;
-                        const bool ok = k < cn[u];
-                        if (ok && (f[u][i] & 1)) {
+                        if (f[u][i] & 1) {  // (f is 0 beyond the run)
                             acc[u].x += x[u][i].x; acc[u].y += x[u][i].y; acc[u].z += x[u][i].z; acc[u].w += x[u][i].w;
                         }
-                        if (ok && (f[u][i] & 2) && c == 0) {  // the rare low-pass centre terms 16..17
+                        if ((f[u][i] & 2) && c == 0) {  // the rare low-pass centre terms 16..17
                             const float2 y = *reinterpret_cast<const float2*>(a.grad_inst + (size_t)(of[u] + k) * GRAD_STRIDE + 16);
                             accB[u].x += y.x; accB[u].y += y.y;
                         }
