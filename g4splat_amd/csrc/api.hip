@@ -31,14 +31,22 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-// One pinned word per host thread for the num_rendered read-back.  hipHostMallocPortable: the same host thread may
-// drive several devices (one process, eight GPUs), and only a portable allocation is pinned for all of them.
+// One pinned, device-mapped word block per host thread for the read-back of the instance counts: the totals kernel
+// stores them straight into host memory (no copy launch between it and the event the host waits on).
+// hipHostMallocPortable: the same host thread may drive several devices (one process, eight GPUs), and only a portable
+// allocation is pinned / mapped for all of them.
 uint32_t* pinned_word() {
     thread_local uint32_t* p = nullptr;
     if (!p) {
-        if (hipHostMalloc((void**)&p, 64, hipHostMallocPortable) != hipSuccess) p = nullptr;
+        if (hipHostMalloc((void**)&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) p = nullptr;
     }
     return p;
+}
+// its address as the current device sees it
+uint32_t* pinned_word_device(uint32_t* host) {
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) return nullptr;
+    return (uint32_t*)d;
 }
 
 // One event per host thread and device, recorded behind the read-back copy: the forward waits on it instead of on
@@ -287,27 +295,25 @@ static int rasterizer_forward_impl(
         // is sized for the Gaussians that actually emit instances.
         uint32_t* idx_block_offs = (uint32_t*)(geom + GL.idx_block_offs);
         uint32_t* vis_block_offs = (uint32_t*)(geom + GL.vis_block_offs);
-        { ProfScope ps(PF_COUNT_SCAN, stream);
-          launch_scan_totals(pa.idx_block_sums, idx_block_offs, pa.ref_block_sums, pa.vis_block_sums, vis_block_offs,
-                             d_total, GL.nblocks, ranges, tiles * 2, stream, presized ? (uint32_t)capacity : 0xFFFFFFFFu); }
-        CHECK_LAUNCH("scan totals");
         uint32_t* h_total = nullptr;
+        uint32_t* h_total_dev = nullptr;
         hipEvent_t totals_ready = nullptr;
         if (!presized) {
             h_total = pinned_word();
-            if (!h_total) return fail(G4S_ERR_HIP, "hipHostMalloc failed");
+            h_total_dev = h_total ? pinned_word_device(h_total) : nullptr;
+            if (!h_total || !h_total_dev) return fail(G4S_ERR_HIP, "hipHostMalloc / hipHostGetDevicePointer failed");
             totals_ready = readback_event();
             if (!totals_ready) return fail(G4S_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(hipMemcpyAsync(h_total, d_total, 12, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipEventRecord(totals_ready, stream));
-        } else if (status_dev) {
-            // status[0] = num_rendered (the reference's count), [1] = instances binned, [2] = emitting Gaussians,
-            // [3] = 1 if the binned instances exceed `capacity` (the frame is then incomplete)
-            HIP_TRY(hipMemcpyAsync(status_dev, d_total + 1, 4, hipMemcpyDeviceToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(status_dev + 1, d_total, 4, hipMemcpyDeviceToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(status_dev + 2, d_total + 2, 4, hipMemcpyDeviceToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(status_dev + 3, d_total + 4, 4, hipMemcpyDeviceToDevice, stream));
         }
+        { ProfScope ps(PF_COUNT_SCAN, stream);
+          launch_scan_totals(pa.idx_block_sums, idx_block_offs, pa.ref_block_sums, pa.vis_block_sums, vis_block_offs,
+                             d_total, GL.nblocks, ranges, tiles * 2, stream, presized ? (uint32_t)capacity : 0xFFFFFFFFu,
+                             h_total_dev, presized ? status_dev : nullptr); }
+        CHECK_LAUNCH("scan totals");
+        if (!presized) {
+            HIP_TRY(hipEventRecord(totals_ready, stream));  // (the kernel above stored the three counts in host memory)
+        }
+        // (presized: the kernel wrote status_dev[0..3] = num_rendered, instances binned, emitting Gaussians, overflow flag)
 
         // Queued BEFORE the host waits for the totals: nothing below needs them on the host -- the gradient slots do
         // not depend on them, and the pack / depth sort / count of the emitting Gaussians read V (d_total[2]) on the

@@ -249,7 +249,9 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
                                                                const uint32_t* __restrict__ ref_sums,
                                                                uint32_t* __restrict__ total_a, uint32_t* __restrict__ total_b,
                                                                uint32_t* __restrict__ zero_ptr, int zero_words,
-                                                               const uint32_t* __restrict__ d_n, uint32_t capacity) {
+                                                               const uint32_t* __restrict__ d_n, uint32_t capacity,
+                                                               uint32_t* __restrict__ host_out,
+                                                               uint32_t* __restrict__ status_out) {
     __shared__ uint32_t wa[16], wb[16], wr[16];
     const int t = (int)threadIdx.x;
     for (int i = t; i < zero_words; i += 1024) zero_ptr[i] = 0u;
@@ -291,6 +293,17 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
             total_b[1] = all_a < capacity ? all_a : capacity;
             total_b[2] = all_a > capacity ? 1u : 0u;
         }
+        if (status_out != nullptr) {  // g4s_rasterizer_forward_presized: the caller's device status words
+            status_out[0] = all_r;
+            status_out[1] = all_a;
+            status_out[2] = all_b;
+            status_out[3] = all_a > capacity ? 1u : 0u;
+        }
+        if (host_out != nullptr) {  // pinned, device-mapped host words: the read-back without a copy launch
+            host_out[0] = all_a;
+            host_out[1] = all_r;
+            host_out[2] = all_b;
+        }
     }
 }
 
@@ -302,7 +315,7 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
                        block_sums, rank_local, d_n);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, total, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, 0, d_n, 0xFFFFFFFFu);
+                       (uint32_t*)nullptr, 0, d_n, 0xFFFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
 // Load-balanced expansion, partitioned by OUTPUT: a block owns EMIT_SLOTS consecutive instance slots, whatever
@@ -440,12 +453,13 @@ void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32
 
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
-                        uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity) {
+                        uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity, uint32_t* host_out,
+                        uint32_t* status_out) {
     // total[0] = instances binned, total[1] = the reference's num_rendered, total[2] = emitting Gaussians,
     // total[3] = min(total[0], capacity), total[4] = 1 if total[0] > capacity
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
                        vis_block_sums, vis_block_offs, ref_block_sums, total, total + 2, zero_ptr, zero_words,
-                       (const uint32_t*)nullptr, capacity);
+                       (const uint32_t*)nullptr, capacity, host_out, status_out);
 }
 
 void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,

@@ -156,7 +156,8 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
 // total[2] = number of emitting Gaussians.  Also clears zero_words 32-bit words at zero_ptr (the tile ranges).
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
-                        uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity = 0xFFFFFFFFu);
+                        uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity = 0xFFFFFFFFu,
+                        uint32_t* host_out = nullptr, uint32_t* status_out = nullptr);
 // Index-order pass: gradient-record slots (rec[idx].inst_off = exclusive scan of tiles_touched over idx) and the
 // stable compaction of the emitting Gaussians' (depth key, index) pairs.
 void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec,
