@@ -1029,3 +1029,52 @@ void oracle_knn_queries(int P, const float *points, int nq, const int *queries, 
         meanDists[qi] = (best[0] + best[1] + best[2]) / 3.0f;
     }
 }
+
+/* Workload statistics at 4x4-cell granularity (design study for the blend forward, not part of the restatement):
+ * out[0] = (entry, quadrant) pairs with a pixel that passes the alpha test before the pixel's last contributor,
+ * out[1] = (entry, 4x4 cell) pairs with such a pixel, out[2] = such (entry, pixel) pairs,
+ * out[3] = sum over quadrants and 256-entry batches of max over the quadrant's four cells of their pair counts
+ *          (the steps a wave needs if its four 16-lane rows walk their own cell lists and meet at batch ends). */
+void oracle_cell_stats(const OracleState *s, double *out /*4*/) {
+    const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+    double quad_pairs = 0, cell_pairs = 0, pix_pairs = 0, row_steps = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+:quad_pairs,cell_pairs,pix_pairs,row_steps)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        int batch_cells[16];
+        memset(batch_cells, 0, sizeof batch_cells);
+        for (uint32_t i = r0; i < r1; i++) {
+            uint32_t id = s->point_list[i];
+            const float *no = s->normal_opacity + 4 * (size_t)id;
+            int cellhit[16];
+            memset(cellhit, 0, sizeof cellhit);
+            for (int l = 0; l < 256; l++) {
+                int lx = l & 15, ly = l >> 4;
+                int px = tx * 16 + lx, py = ty * 16 + ly;
+                if (px >= W || py >= H) continue;
+                size_t pix = (size_t)W * py + px;
+                if ((i - r0) >= s->n_contrib[pix]) continue;
+                PairEval e;
+                if (!eval_pair((float)px, (float)py, s->means2D + 2 * (size_t)id, s->transMat + 9 * (size_t)id, no[3], &e)) continue;
+                pix_pairs += 1;
+                /* quadrant q = (lx >> 3) + 2 (ly >> 3); cell inside it = ((lx >> 2) & 1) + 2 ((ly >> 2) & 1) */
+                cellhit[((lx >> 3) + 2 * (ly >> 3)) * 4 + ((lx >> 2) & 1) + 2 * ((ly >> 2) & 1)] = 1;
+            }
+            for (int q = 0; q < 4; q++) {
+                int any = 0;
+                for (int c = 0; c < 4; c++) { any |= cellhit[4 * q + c]; cell_pairs += cellhit[4 * q + c]; batch_cells[4 * q + c] += cellhit[4 * q + c]; }
+                quad_pairs += any;
+            }
+            if (((i - r0) & 255) == 255 || i + 1 == r1) {
+                for (int q = 0; q < 4; q++) {
+                    int m = 0;
+                    for (int c = 0; c < 4; c++) if (batch_cells[4 * q + c] > m) m = batch_cells[4 * q + c];
+                    row_steps += m;
+                }
+                memset(batch_cells, 0, sizeof batch_cells);
+            }
+        }
+    }
+    out[0] = quad_pairs; out[1] = cell_pairs; out[2] = pix_pairs; out[3] = row_steps;
+}
