@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from common import cotangents, hip_state, run_hip, run_oracle, scene_inputs  # noqa: E402
-from test_gpu_parity import GRAD_RTOL, OUT_ATOL, check_lists_against_oracle, rel_err  # noqa: E402
+from common import GRAD_RTOL, OUT_ATOL, rel_err  # noqa: E402
+from test_gpu_parity import check_lists_against_oracle  # noqa: E402
 import oracle.oracle as oracle_mod  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
