@@ -190,7 +190,8 @@ def parity_report(h, o, inp, oracle_mod):
                            row_rel_unexplained=float((row_err[big] / row_mag[big]).max()) if big.any() else 0.0,
                            rows_beyond_contract=int((row_err > GRAD_RTOL * scale).sum()),
                            rows_beyond_contract_unexplained=int(((row_err > GRAD_RTOL * scale) & un).sum()),
-                           l2=float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)))
+                           l2=float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30)),
+                           l2_unexplained=float(np.linalg.norm((a - b)[un]) / (np.linalg.norm(b) + 1e-30)))
         rep["grads"] = g
     return rep
 
@@ -209,5 +210,8 @@ def assert_parity(h, o, inp, oracle_mod, tag="", out_atol=OUT_ATOL_GUARD, grad_r
     for name, g in rep.get("grads", {}).items():
         assert g["rel_unexplained"] <= grad_rtol, (tag, name, g)
         assert g["row_rel_unexplained"] <= row_rtol, (tag, name, g)
-        assert g["l2"] <= GRAD_RTOL, (tag, name, g)
+        # relative L2 error of the whole tensor: over the rows no flip can have touched always; over all rows when
+        # nothing flipped (a single flipped pixel moves O(|cotangent|) -- in a one-splat scene that is 0.1 % of everything)
+        assert g["l2_unexplained"] <= GRAD_RTOL, (tag, name, g)
+        assert rep["flipped_pixels"] > 0 or g["l2"] <= GRAD_RTOL, (tag, name, g)
     return rep
