@@ -33,7 +33,7 @@ namespace g4s {
 // step) left the sort bound by partial-line writes: 0.043 ms per pass over 4.4 M instances, against 0.022 now.
 
 template <typename K, int ITEMS>
-__global__ void __launch_bounds__(256) radix_hist_kernel(const K* __restrict__ keys, int n, int shift,
+__global__ void __launch_bounds__(256) radix_hist_kernel(const K* __restrict__ keys, int n, int shift, uint32_t mask,
                                                          uint32_t* __restrict__ hist, int nblocks,
                                                          const uint32_t* __restrict__ d_n) {
     __shared__ uint32_t h[256];
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const K* __restrict__ k
     }
 #pragma unroll
     for (int u = 0; u < ITEMS; u++)
-        if (begin + 256 * u + t < end) atomicAdd(&h[(uint32_t)(k[u] >> shift) & 0xFFu], 1u);
+        if (begin + 256 * u + t < end) atomicAdd(&h[(uint32_t)(k[u] >> shift) & mask], 1u);
     __syncthreads();
     hist[(size_t)t * nblocks + block] = h[t];
 }
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
 template <typename K, bool HAS_VAL, int ITEMS>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                             const uint32_t* __restrict__ vals_in,
-                                                            uint32_t* __restrict__ vals_out, int n, int shift,
+                                                            uint32_t* __restrict__ vals_out, int n, int shift, uint32_t mask,
                                                             const uint32_t* __restrict__ hist,
                                                             const uint32_t* __restrict__ bin_total, int nblocks,
                                                             const uint32_t* __restrict__ d_n) {
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const bool valid = wbegin + 64 * u + lane < end;
-        const uint32_t d = (uint32_t)(key[u] >> shift) & 0xFFu;
+        const uint32_t d = (uint32_t)(key[u] >> shift) & mask;
         uint64_t m = __ballot(valid);  // match-any over the 8 digit bits
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         if (wbegin + 64 * u + lane < end) {
-            const uint32_t d = (uint32_t)(key[u] >> shift) & 0xFFu;
+            const uint32_t d = (uint32_t)(key[u] >> shift) & mask;
             const uint32_t slot = s_cnt[w][d] + lrank[u];
             s_keys[slot] = key[u];
             if (HAS_VAL) s_vals[slot] = val[u];
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
         const int slot = 256 * u + t;
         if (slot < nvalid) {
             const K k = s_keys[slot];
-            const uint32_t dst = s_gbase[(uint32_t)(k >> shift) & 0xFFu] + (uint32_t)slot;
+            const uint32_t dst = s_gbase[(uint32_t)(k >> shift) & mask] + (uint32_t)slot;
             keys_out[dst] = k;
             if (HAS_VAL) vals_out[dst] = s_vals[slot];
         }
@@ -178,14 +178,15 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
 // d_n == nullptr: n keys (host-known).  Otherwise n is read from *d_n by the kernels and only bounds the grid
 // (n_max >= *d_n): the launches can be queued before the host knows the count.
 template <typename K, bool HAS_VAL, int ITEMS>
-static void radix_pass(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int n, int shift, uint32_t* hist,
+static void radix_pass(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int n, int shift, int bits, uint32_t* hist,
                        uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr) {
     constexpr int TK = 256 * ITEMS;
     const int nblocks = (n + TK - 1) / TK;
-    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nblocks), dim3(256), 0, s, kin, n, shift, hist, nblocks, d_n);
+    const uint32_t mask = (1u << bits) - 1u;  // digit width <= 8 bits (256 histogram rows; rows above the mask stay empty)
+    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nblocks), dim3(256), 0, s, kin, n, shift, mask, hist, nblocks, d_n);
     hipLaunchKernelGGL(radix_scan_kernel<TK>, dim3(256), dim3(256), 0, s, hist, nblocks, bin_total, d_n);
     hipLaunchKernelGGL((radix_scatter_kernel<K, HAS_VAL, ITEMS>), dim3(nblocks), dim3(256), 0, s, kin, kout, vin, vout, n,
-                       shift, hist, bin_total, nblocks, d_n);
+                       shift, mask, hist, bin_total, nblocks, d_n);
 }
 
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
@@ -194,23 +195,27 @@ int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
     int cur = 0;
     for (int shift = 0; shift < 32; shift += 8) {
         if (cur == 0)
-            radix_pass<uint32_t, true, SORT_ITEMS_U32>(keys_a, keys_b, vals_a, vals_b, n, shift, hist, bin_total, s, d_n);
+            radix_pass<uint32_t, true, SORT_ITEMS_U32>(keys_a, keys_b, vals_a, vals_b, n, shift, 8, hist, bin_total, s, d_n);
         else
-            radix_pass<uint32_t, true, SORT_ITEMS_U32>(keys_b, keys_a, vals_b, vals_a, n, shift, hist, bin_total, s, d_n);
+            radix_pass<uint32_t, true, SORT_ITEMS_U32>(keys_b, keys_a, vals_b, vals_a, n, shift, 8, hist, bin_total, s, d_n);
         cur ^= 1;
     }
     return cur;
 }
 
+// Stable partition on bits [begin_bit, end_bit): ceil(bits / 8) passes of EQUAL width (13 tile bits -> 7 + 6 rather than
+// 8 + 5: with 32 bins the second pass' 64 lanes fight over too few LDS counters in the histogram).
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
                         uint32_t* bin_total, hipStream_t s, const uint32_t* d_n) {
-    if (n <= 0) return 0;
+    if (n <= 0 || end_bit <= begin_bit) return 0;
+    const int bits = end_bit - begin_bit, passes = (bits + 7) / 8, per = (bits + passes - 1) / passes;
     int cur = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    for (int shift = begin_bit; shift < end_bit; shift += per) {
+        const int nb = per < end_bit - shift ? per : end_bit - shift;
         if (cur == 0)
-            radix_pass<uint64_t, false, SORT_ITEMS_U64>(a, b, nullptr, nullptr, n, shift, hist, bin_total, s, d_n);
+            radix_pass<uint64_t, false, SORT_ITEMS_U64>(a, b, nullptr, nullptr, n, shift, nb, hist, bin_total, s, d_n);
         else
-            radix_pass<uint64_t, false, SORT_ITEMS_U64>(b, a, nullptr, nullptr, n, shift, hist, bin_total, s, d_n);
+            radix_pass<uint64_t, false, SORT_ITEMS_U64>(b, a, nullptr, nullptr, n, shift, nb, hist, bin_total, s, d_n);
         cur ^= 1;
     }
     return cur;
@@ -471,23 +476,37 @@ void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* 
                        gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit, rec_flag, d_counts);
 }
 
-// rasterizer_impl.cu:116-138 on the packed entries (ranges pre-zeroed by the caller, :311)
+// rasterizer_impl.cu:116-138 on the packed entries (ranges pre-zeroed, :311).  Four consecutive entries per thread
+// (two 16-byte loads + the predecessor): a quarter of the workgroups and of the loads of the one-entry form.
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int R, const uint64_t* __restrict__ entries,
                                                           uint32_t* __restrict__ ranges, const uint32_t* __restrict__ d_n) {
-    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (d_n != nullptr) R = (int)*d_n;
-    if (i >= R) return;
-    const uint32_t cur = entry_tile(entries[i]);
-    if (i == 0) {
-        ranges[2 * cur] = 0;
+    const int i0 = (int)(blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= R) return;
+    uint64_t e[4];
+    if (i0 + 4 <= R) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(entries + i0);
+        const ulonglong2 b = *reinterpret_cast<const ulonglong2*>(entries + i0 + 2);
+        e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y;
     } else {
-        const uint32_t prev = entry_tile(entries[i - 1]);
-        if (cur != prev) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = entries[i0 + k < R ? i0 + k : R - 1];
+    }
+    uint32_t prev = i0 > 0 ? entry_tile(entries[i0 - 1]) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = i0 + k;
+        if (i >= R) break;
+        const uint32_t cur = entry_tile(e[k]);
+        if (i == 0) {
+            ranges[2 * cur] = 0;
+        } else if (cur != prev) {
             ranges[2 * prev + 1] = (uint32_t)i;
             ranges[2 * cur] = (uint32_t)i;
         }
+        if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
+        prev = cur;
     }
-    if (i == R - 1) ranges[2 * cur + 1] = (uint32_t)R;
 }
 
 // Processing order of the tiles: longest instance list first (LPT scheduling).  A tile is one
@@ -533,7 +552,7 @@ void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, 
 
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s, const uint32_t* d_n) {
     if (R <= 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, entries, ranges, d_n);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 1023) / 1024), dim3(256), 0, s, R, entries, ranges, d_n);
 }
 
 }  // namespace g4s
