@@ -502,8 +502,6 @@ static int rasterizer_backward_impl(
     if (radii == nullptr) radii = (const int*)(geom + GL.internal_radii);
     float* grad_inst = (float*)align_ptr(workspace);
 
-    // (dL_dsh is mostly zero rows -- invisible Gaussians; K8's fold kernel clears exactly those rows while it waits for
-    // its gather, K8b writes the others: no memset of the 192 B x P tensor)
     // gradient records: only instances that receive a contribution are written by the blend backward; instead of
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
     // the deep-tile counter + list sit behind the records; the counter is cleared by the tile-order kernel below
@@ -513,6 +511,7 @@ static int rasterizer_backward_impl(
     // and were cleared by the forward (emit).  A second backward over the same forward state finds them set -- to the
     // values it is going to write again (which records are written depends on the forward's state only).
     uint8_t* rec_flag = nullptr;
+    bool sh_prezeroed = false;
     if (R > 0) {
         char* bin = align_ptr(binning_buffer);
         rec_flag = (uint8_t*)(bin + BL.rec_flag);
@@ -543,6 +542,21 @@ static int rasterizer_backward_impl(
         bb.hot_threshold = getenv("G4S_BWD_HOT_THRESHOLD") ? atoi(getenv("G4S_BWD_HOT_THRESHOLD"))
                            : (tiles <= BWD_FOUR_WAVE_MAX_TILES ? -1 : (int)(outlier < 0x7fffffff ? outlier : 0x7fffffff));
         bb.hot_count = hot_count; bb.hot_list = hot_list;
+        // dL_dsh is mostly zero rows (invisible Gaussians).  When the one-wave kernel runs, its workgroups clear the
+        // tensor on the side (blend.hip) and K8 writes the visible rows only; otherwise K8 clears the rows it skips.
+        if (bb.hot_threshold >= 0 && M > 0 && !getenv("G4S_NO_SIDE_ZERO")) {
+            float* zb[2] = {dL_dsh, dL_dsh_rest};
+            const size_t zn[2] = {(size_t)P * (dL_dsh_rest ? 1 : M) * 3, dL_dsh_rest ? (size_t)P * (M - 1) * 3 : 0};
+            bool ok = true;
+            for (int z = 0; z < 2; z++) ok = ok && (zn[z] == 0 || (!misaligned(zb[z], 16) && (zn[z] >> 2) <= 0xffffffffull));
+            if (ok) {
+                for (int z = 0; z < 2; z++) {
+                    if (zn[z] == 0) continue;
+                    bb.zero_base[z] = zb[z]; bb.zero_quads[z] = (uint32_t)(zn[z] >> 2); bb.zero_tail[z] = (uint32_t)(zn[z] & 3);
+                }
+                sh_prezeroed = true;
+            }
+        }
         { ProfScope ps(PF_BLEND_BWD, stream); launch_blend_bwd(bb, stream); }
         CHECK_LAUNCH("blend_bwd");
     }
@@ -559,7 +573,7 @@ static int rasterizer_backward_impl(
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
     pb.rec_flag = rec_flag;
-    pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest;
+    pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest; pb.sh_prezeroed = sh_prezeroed;
     pb.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dtransMat = dL_dtransMat; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;

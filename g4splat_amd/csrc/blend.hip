@@ -270,7 +270,7 @@ struct BwdPixelLite {  // what stays in registers per pixel; the rest of BwdPixe
     float dpx0, dpx1, dpx2, dL_ddepth, dL_daccum, dn0, dn1, dn2;
     float T, V_rec, last_dL_dT;
 };
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_bwd_kernel(BlendBwdArgs a) {
+__device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
     __shared__ float4 s_rec[BLEND_QUADS][BWD1_BATCH];  // the culling quads are not needed here
     __shared__ uint32_t s_slot[BWD1_BATCH];
     __shared__ float4 s_cst[256];   // per pixel (quadrant * 64 + lane): A2, D2, C2, nTfbg
@@ -491,6 +491,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 if (lane == 0) a.rec_flag[slot] = lp ? 3 : 1;
             }
         }
+    }
+}
+
+// The kernel proper: the tile, then this workgroup's share of the zero-fill (BlendBwdArgs::zero_*).  The tile work is
+// VALU-bound and HBM is nearly idle under it; the stores of a finished wave drain while the others compute, which
+// takes 207 MB of zero rows (72 % of dL_dsh at the metric size) out of the HBM-bound K8 behind this kernel.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_bwd_kernel(BlendBwdArgs a) {
+    blend_bwd_tile(a);
+    const uint32_t lane = threadIdx.x, first = blockIdx.x * 64 + lane, stride = gridDim.x * 64;
+#pragma unroll
+    for (int z = 0; z < 2; z++) {
+        float4* b = reinterpret_cast<float4*>(a.zero_base[z]);
+        if (b == nullptr) continue;
+        const uint32_t nq = a.zero_quads[z];
+        for (uint32_t i = first; i < nq; i += stride) b[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.x == 0 && lane < a.zero_tail[z]) reinterpret_cast<float*>(b + nq)[lane] = 0.0f;
     }
 }
 

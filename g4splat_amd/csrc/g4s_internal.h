@@ -209,6 +209,12 @@ struct BlendBwdArgs {
     int hot_threshold;  // < 0: all tiles go to the four-wave kernel (frames with too few tiles to fill the GPU one wave each)
     uint32_t* hot_count;
     uint32_t* hot_list;  // tiles entries
+    // Zero-fill riding along with the one-wave kernel (which is VALU-bound and leaves HBM idle): up to two float
+    // ranges (dL_dsh, or its dc / rest parts) that every workgroup clears a 1/grid share of when its tile is done.
+    // K8 then writes the rows of visible Gaussians only.  zero_base == NULL: nothing to clear.
+    float* zero_base[2];      // 16-byte aligned
+    uint32_t zero_quads[2];   // float4 count
+    uint32_t zero_tail[2];    // 0..3 floats behind the quads
 };
 constexpr int BWD_HOT_THRESHOLD = 2048;  // live list positions; override for tests: G4S_BWD_HOT_THRESHOLD
 constexpr int BWD_FOUR_WAVE_MAX_TILES = 768;  // frames with at most this many tiles use the four-wave kernel throughout
@@ -226,6 +232,7 @@ struct PreprocessBwdArgs {
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
     const float* shs_rest;  // split layout: shs / dL_dsh are the [P,1,3] parts, shs_rest / dL_dsh_rest the [P,M-1,3] ones
     float* dL_dsh_rest;
+    bool sh_prezeroed;  // dL_dsh (and dL_dsh_rest) were cleared by the blend backward: K8 writes visible rows only
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
         *dL_drot;
 };

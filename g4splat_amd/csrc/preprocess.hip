@@ -583,6 +583,10 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
 // floats of a record (coalesced 72-byte runs) and land in LDS.  Phase 2 is one thread per
 // Gaussian.  Every output element is written (zeros for invisible Gaussians).
 constexpr int K8_SUM_STRIDE = GRAD_FLOATS + 1;  // LDS row stride, odd => conflict-free column reads
+// LDS staging of the block's outputs (floats per Gaussian: mean2D 3, normal 3, opacity 1, colour 3, mean3D 3, T 9, scale 2,
+// rotation 4 = 28), one row-major [256, w] region per tensor
+constexpr int K8_OUT_MEAN2D = 0, K8_OUT_NORMAL = 768, K8_OUT_OPACITY = 1536, K8_OUT_COLOR = 1792, K8_OUT_MEAN3D = 2560,
+              K8_OUT_TRANSMAT = 3328, K8_OUT_SCALE = 5632, K8_OUT_ROT = 6144, K8_OUT_FLOATS = 28;
 
 // K8, phase 1: the fold.
 //
@@ -786,7 +790,10 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
 // (16-lane rows) that round trip was the larger cost.
 template <int SH_MODE>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a, FoldShZero z0, FoldShZero z1) {
-    __shared__ float s_sum[256 * K8_SUM_STRIDE];
+    // one LDS buffer, used twice: the folded terms (256 x 19 floats) of phase 1, then the block's 256 x 28 output floats
+    // on their way to coalesced 16-byte stores (K8_OUT_* below)
+    __shared__ float s_buf[256 * K8_OUT_FLOATS];
+    float* s_sum = s_buf;
     __shared__ uint32_t s_off[256], s_cnt[256];
     __shared__ uint8_t s_vis[256];
     const int t = (int)threadIdx.x;
@@ -795,7 +802,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     fold_block(a, z0, z1, s_sum, s_off, s_cnt, s_vis);
     const bool visible = s_vis[t] != 0;
     const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)(in_range ? idx : 0) * REC_QUADS;
-    if (!in_range) return;
 
     // record order (blend backward): 0..14 = colour, normal, T; 15 = opacity; 16..17 = low-pass centre terms
     float g[GRAD_FLOATS];
@@ -925,22 +931,53 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     }
     // rows of dL_dsh that belong to invisible Gaussians were cleared by fold_records_kernel (coalesced, block-wide)
 
-    a.dL_dmean2D[3 * idx] = dmean2[0]; a.dL_dmean2D[3 * idx + 1] = dmean2[1]; a.dL_dmean2D[3 * idx + 2] = dmean2[2];
-    if (a.dL_dnormal) { a.dL_dnormal[3 * idx] = g[3]; a.dL_dnormal[3 * idx + 1] = g[4]; a.dL_dnormal[3 * idx + 2] = g[5]; }
-    a.dL_dopacity[idx] = g[17];
-    a.dL_dcolor[3 * idx] = g[0]; a.dL_dcolor[3 * idx + 1] = g[1]; a.dL_dcolor[3 * idx + 2] = g[2];
-    a.dL_dmean3D[3 * idx] = dmean3[0]; a.dL_dmean3D[3 * idx + 1] = dmean3[1]; a.dL_dmean3D[3 * idx + 2] = dmean3[2];
+    // Outputs: every thread parks its 28 floats in LDS, then the block writes each tensor's 256-row region with
+    // coalesced 16-byte stores -- 7 store instructions per thread instead of 28 strided dword stores, three quarters of
+    // which only carried the zeros of invisible Gaussians.
+    __syncthreads();  // every thread has taken its folded terms out of s_buf
+    {
+        float* o = s_buf;
+        o[K8_OUT_MEAN2D + 3 * t] = dmean2[0]; o[K8_OUT_MEAN2D + 3 * t + 1] = dmean2[1]; o[K8_OUT_MEAN2D + 3 * t + 2] = dmean2[2];
+        o[K8_OUT_NORMAL + 3 * t] = g[3]; o[K8_OUT_NORMAL + 3 * t + 1] = g[4]; o[K8_OUT_NORMAL + 3 * t + 2] = g[5];
+        o[K8_OUT_OPACITY + t] = g[17];
+        o[K8_OUT_COLOR + 3 * t] = g[0]; o[K8_OUT_COLOR + 3 * t + 1] = g[1]; o[K8_OUT_COLOR + 3 * t + 2] = g[2];
+        o[K8_OUT_MEAN3D + 3 * t] = dmean3[0]; o[K8_OUT_MEAN3D + 3 * t + 1] = dmean3[1]; o[K8_OUT_MEAN3D + 3 * t + 2] = dmean3[2];
 #pragma unroll
-    for (int i = 0; i < 9; i++) a.dL_dtransMat[9 * (size_t)idx + i] = dT_out[i];
-    reinterpret_cast<float2*>(a.dL_dscale)[idx] = make_float2(dscale[0], dscale[1]);
-    reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+        for (int i = 0; i < 9; i++) o[K8_OUT_TRANSMAT + 9 * t + i] = dT_out[i];
+        o[K8_OUT_SCALE + 2 * t] = dscale[0]; o[K8_OUT_SCALE + 2 * t + 1] = dscale[1];
+        *reinterpret_cast<float4*>(o + K8_OUT_ROT + 4 * t) = drot;
+    }
+    __syncthreads();
+    {
+        const int rows = imin_(256, a.P - (int)blockIdx.x * 256);
+        auto flush = [&](float* base, int w, int lds_off) {
+            if (base == nullptr) return;
+            float* dst = base + (size_t)blockIdx.x * 256 * w;
+            const float* src = s_buf + lds_off;
+            const int n = rows * w;
+            if ((((size_t)dst) & 15) == 0) {
+                for (int i = t; i < (n >> 2); i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+                for (int i = (n & ~3) + t; i < n; i += 256) dst[i] = src[i];
+            } else {
+                for (int i = t; i < n; i += 256) dst[i] = src[i];
+            }
+        };
+        flush(a.dL_dmean2D, 3, K8_OUT_MEAN2D);
+        flush(a.dL_dnormal, 3, K8_OUT_NORMAL);
+        flush(a.dL_dopacity, 1, K8_OUT_OPACITY);
+        flush(a.dL_dcolor, 3, K8_OUT_COLOR);
+        flush(a.dL_dmean3D, 3, K8_OUT_MEAN3D);
+        flush(a.dL_dtransMat, 9, K8_OUT_TRANSMAT);
+        flush(a.dL_dscale, 2, K8_OUT_SCALE);
+        flush(a.dL_drot, 4, K8_OUT_ROT);
+    }
 }
 
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     // dL_dsh rows of the Gaussians phase 2 does not write are cleared by the fold phase (no separate memset)
     FoldShZero z0{nullptr, 0}, z1{nullptr, 0};
-    if (a.M > 0 && a.dL_dsh != nullptr) {
+    if (a.M > 0 && a.dL_dsh != nullptr && !a.sh_prezeroed) {
         if (a.shs_rest != nullptr) {
             z0 = FoldShZero{a.dL_dsh, 3};
             if (a.M > 1) z1 = FoldShZero{a.dL_dsh_rest, (a.M - 1) * 3};

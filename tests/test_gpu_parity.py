@@ -623,3 +623,48 @@ def test_presized_forward_never_blocks_the_host_and_matches(hip_lib):
     assert st[3] == 1 and st[0] == R, st
     fw = presized(state, a["sh"])
     assert state.status.tolist()[3] == 0 and np.array_equal(fw[1].cpu().numpy(), base["color"])
+
+
+@pytest.mark.parametrize("P", [20001, 20003])
+def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P, monkeypatch):
+    """dL_dsh is mostly zero rows (invisible Gaussians).  In frames that run the one-wave blend backward those rows are
+    cleared by that kernel's workgroups on the side (api.hip / blend.hip: BlendBwdArgs::zero_*), elsewhere by K8 itself
+    (G4S_NO_SIDE_ZERO forces that path).  Both must write every element of caller-provided, NaN-filled outputs and
+    agree bit for bit -- packed SH and split SH, row counts that leave 0..3 floats behind the last 16-byte store."""
+    import torch
+    from g4splat_amd.diff_surfel_rasterization import _C
+    inp = scene_inputs(P=P, W=640, H=480, seed=23, D=3, bg=(0.1, 0.2, 0.3))  # 1 200 tiles: the one-wave kernel runs
+    gr = cotangents(480, 640, seed=6)
+    base = run_hip(inp, gr)
+    assert (base["radii"] == 0).sum() > P // 10  # there ARE invisible rows
+    a = base["args"]
+    t = lambda x: torch.as_tensor(x, device="cuda:0")
+    results = {}
+    for side in (True, False):
+        if side:
+            monkeypatch.delenv("G4S_NO_SIDE_ZERO", raising=False)
+        else:
+            monkeypatch.setenv("G4S_NO_SIDE_ZERO", "1")
+        for split in (False, True):
+            sh = (a["sh"][:, :1].contiguous(), a["sh"][:, 1:].contiguous()) if split else a["sh"]
+            fw = _C.rasterize_gaussians(a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"], a["rotations"], 1.0,
+                                        a["transMat"], a["view"], a["proj"], inp["tanfovx"], inp["tanfovy"], inp["H"],
+                                        inp["W"], sh, inp["D"], a["campos"], False, False)
+            R, color, others, radii, geom, binning, img = fw
+            nan = lambda *s: torch.full(s, float("nan"), device="cuda:0")
+            out = {"dL_dsh_dc": nan(P, 1, 3), "dL_dsh_rest": nan(P, 15, 3)} if split else {"dL_dsh": nan(P, 16, 3)}
+            g = _C.rasterize_gaussians_backward(a["bg"], a["means3D"], radii, a["colors"], a["scales"], a["rotations"], 1.0,
+                                                a["transMat"], a["view"], a["proj"], inp["tanfovx"], inp["tanfovy"],
+                                                t(gr[0]), t(gr[1]), sh, inp["D"], a["campos"], geom, R, binning, img, False,
+                                                out=out)
+            dsh = g[5]
+            if split:
+                assert dsh[0].data_ptr() == out["dL_dsh_dc"].data_ptr() and dsh[1].data_ptr() == out["dL_dsh_rest"].data_ptr()
+                dsh = torch.cat(list(dsh), dim=1)
+            else:
+                assert dsh.data_ptr() == out["dL_dsh"].data_ptr()
+            results[(side, split)] = dsh.cpu().numpy()
+    for key, v in results.items():
+        assert not np.isnan(v).any(), key
+        assert np.array_equal(v, base["grads"]["sh"]), key
+        assert np.all(v[base["radii"] == 0] == 0), key
