@@ -105,6 +105,7 @@ def main():
     if world > 1 or os.environ.get("G4S_FORCE_DIST"):  # G4S_FORCE_DIST: exercise the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # (torch.distributed.run sets both; this is for G4S_FORCE_DIST)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:

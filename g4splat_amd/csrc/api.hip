@@ -833,6 +833,8 @@ extern "C" int g4s_pack_rows(int nseg, float* const* segments, const int* widths
     const int debug = 0;
     t_err[0] = 0;
     if (nseg < 1 || nseg > 8 || n < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "1..8 segments, n >= 0");
+    if (unpack < 0 || unpack > 7 || ((unpack & 4) && !(unpack & 1)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "mode: bit 0 unpack, bit 1 row-major buffer, bit 2 add (unpack only)");
     if (!segments || !widths || (n > 0 && (!row_index || !packed))) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
     for (int i = 0; i < nseg; i++)
         if (!segments[i] || widths[i] <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: NULL pointer or width <= 0", i);

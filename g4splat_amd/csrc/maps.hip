@@ -291,7 +291,11 @@ extern "C" void g4s_maps_launch_internal(int fwd, int W, int H, float depth_rati
 }
 
 // ---- packed rows for the visible-rows gradient exchange (g4splat_amd/parallel.py) -----------------
-// pack:   packed[seg_off(s) * n + j * w_s + c] = seg_s[idx[j] * w_s + c]      (unpack: the reverse)
+// mode bit 0: direction (0 = pack: rows -> buffer, 1 = unpack: buffer -> rows)
+// mode bit 1: buffer layout (0 = segment after segment, packed[seg_off(s) * n + j * w_s + c]; 1 = row-major [n, sum w],
+//             packed[j * sum_w + seg_off(s) + c] -- what an all_to_all with per-destination row ranges needs)
+// mode bit 2: unpack ADDS to the rows instead of overwriting them (the owner's accumulation of one source's rows; a
+//             source holds a row at most once, so there are no duplicate indices inside one launch)
 // A row's floats over all segments (58 + 2 for the gradient bucket) are spread over the lanes of a wave --
 // lane -> (segment, column) is fixed for the whole kernel, so there is no per-element division -- and each wave
 // walks rows j, j + #waves, ...: both sides move contiguous w_s-float runs.  Rows wider than 64 floats take
@@ -303,16 +307,17 @@ struct RowSegs {
     int nseg;
 };
 __global__ void __launch_bounds__(256) pack_rows_kernel(RowSegs segs, const long long* __restrict__ idx, int n,
-                                                        float* __restrict__ packed, int unpack) {
+                                                        float* __restrict__ packed, int mode) {
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = (int)(gridDim.x * 4);
+    const bool unpack = (mode & 1) != 0, row_major = (mode & 2) != 0, add = (mode & 4) != 0;
     int row_floats = 0;
     for (int s = 0; s < segs.nseg; s++) row_floats += segs.width[s];
     for (int f0 = 0; f0 < row_floats; f0 += 64) {
         // this lane's (segment, column) for float f0 + lane of a row
         const int f = f0 + lane;
         int seg = -1, col = 0, w = 1;
-        size_t seg_off = 0;  // floats of the packed buffer before this segment, per row of n
+        size_t seg_off = 0;  // floats of a row before this segment
         {
             int base = 0;
             size_t off = 0;
@@ -324,22 +329,25 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(RowSegs segs, const long
         }
         if (seg < 0) continue;
         float* sp = segs.ptr[seg];
-        float* pp = packed + seg_off * (size_t)n + col;
+        float* pp = row_major ? packed + f : packed + seg_off * (size_t)n + col;
+        const size_t pstride = row_major ? (size_t)row_floats : (size_t)w;
         for (int j = wave; j < n; j += nwaves) {
             float* src = sp + (size_t)idx[j] * w + col;
-            float* dst = pp + (size_t)j * w;
-            if (unpack) *src = *dst; else *dst = *src;
+            float* dst = pp + (size_t)j * pstride;
+            if (!unpack) *dst = *src;
+            else if (add) *src += *dst;
+            else *src = *dst;
         }
     }
 }
 }  // namespace g4s
 
 extern "C" void g4s_pack_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, const long long* idx, int n,
-                                              float* packed, int unpack, hipStream_t s) {
+                                              float* packed, int mode, hipStream_t s) {
     RowSegs segs{};
     segs.nseg = nseg;
     for (int i = 0; i < nseg; i++) { segs.ptr[i] = ptrs[i]; segs.width[i] = widths[i]; }
     if (n <= 0) return;
     const int blocks = (n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192;  // >= 8 rows per wave once n is large
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, s, segs, idx, n, packed, unpack);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, s, segs, idx, n, packed, mode);
 }

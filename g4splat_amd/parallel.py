@@ -10,6 +10,7 @@ restricted to the rows of Gaussians visible on some rank when those are a minori
 a norm per view, not the norm of a sum), visibility counts are summed, radii are max-reduced
 (train_with_refine_depth.py:583).
 """
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import torch
@@ -123,24 +124,33 @@ class OwnerReduce:
       begin(visible)   right after the forward (the radii are known): the indices of this rank's visible rows, their
                        per-owner counts, an all_gather of the counts (world ints per rank) and an asynchronous copy of
                        the count matrix to the host -- all of it overlaps the backward, so the sizes are on the host
-                       long before they are needed and nothing stalls on them (no `nonzero()` anywhere: the index list has a fixed, padded size);
-      finish()         after the backward: pack this rank's visible rows (one g4s_pack_rows launch on a HIP device),
-                       ONE all_to_all (uneven splits) of rows + ONE of their indices to the owners; the owner adds what
-                       it received to its shard in ascending source-rank order (fixed order => bit-reproducible); then
-                       ONE all_gather of the reduced shards puts the full reduced gradient on every rank.
+                       long before they are needed and nothing stalls on them (no `nonzero()` anywhere: the index list
+                       has a fixed, padded size);
+      finish()         after the backward: pack this rank's visible rows row-major (ONE g4s_pack_rows launch on a HIP
+                       device), ONE all_to_all (uneven splits) of rows + ONE of their indices to the owners; the owner
+                       adds what it received from the other ranks INTO ITS OWN SLICE of the gradient tensors, source by
+                       source in ascending rank order (fixed order => bit-reproducible; one accumulating g4s_pack_rows
+                       launch per source); then the reduced shards are all-gathered IN PLACE, one collective per
+                       tensor straight into the gradient tensors (rank d's slice of a [P, w] tensor is contiguous) --
+                       no staging buffer, no copy back.  (P not divisible by the world size: the shards are ragged and
+                       the gather goes through a padded staging buffer instead.)
 
     Bytes through a rank's links per step, P Gaussians, w floats per row, visible fraction v, N ranks:
-        all_to_all   v P (N-1)/N (4 w + 4)      sent and received     (dense reduce-scatter: P (N-1)/N 4 w)
+        all_to_all   v P (N-1)/N (4 w + 8)      sent and received     (dense reduce-scatter: P (N-1)/N 4 w)
         all_gather   P (N-1)/N 4 w              received, P/N 4 w sent to each peer
-    At P = 1.5 M, w = 60, v = 0.28, N = 8: 90 MB + 315 MB instead of 2 x 315 MB for the dense all-reduce, and both
+    At P = 1.5 M, w = 60, v = 0.28, N = 8: 91 MB + 315 MB instead of 2 x 315 MB for the dense all-reduce, and both
     collectives are all-pairs patterns that use the seven xGMI links of a GPU concurrently (a ring all-reduce is bound
-    by one link).  The result equals the dense all-reduce up to the order of the (at most N) additions per element;
-    with two ranks it is bit-identical.  Rows that no rank sees stay exactly zero.
+    by one link).  Local HBM traffic on top of that: the packed rows once each way (2 x v P 4 w), nothing else.
+    The result equals the dense all-reduce up to the order of the (at most N) additions per element; with two ranks it
+    is bit-identical.  Rows that no rank sees stay exactly zero.
 
     Valid while a rank's gradient rows are zero outside its `visible` set (pure render gradients)."""
 
     def __init__(self, row_views: Sequence[torch.Tensor], group=None):
         self.rows, self.group = list(row_views), group
+        for r in self.rows:
+            if r.ndim != 2 or not r.is_contiguous() or r.dtype != torch.float32:
+                raise RuntimeError("OwnerReduce: row views must be contiguous float32 [P, w] tensors")
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.P = int(self.rows[0].shape[0])
@@ -149,10 +159,18 @@ class OwnerReduce:
         self.shard = (self.P + self.world - 1) // self.world  # rows per owner (the last shard may be short)
         dev = self.rows[0].device
         self.dev = dev
+        self.hip = dev.type == "cuda"
+        self.even = self.P == self.world * self.shard  # equal shards: the reduced slices are gathered in place
         self._counts_host = None
         self._event = None
         self._idx = None
-        self._gather = torch.zeros(self.world * self.shard, self.width, device=dev)  # all_gather target (padded shards)
+        self._gather = self._acc = None
+        self._edges = torch.tensor([min(d * self.shard, self.P) for d in range(self.world + 1)], dtype=torch.int64, device=dev)
+        if not self.even:  # ragged shards: all_gather of padded shards through a staging buffer
+            self._gather = torch.zeros(self.world * self.shard, self.width, device=dev)
+            self._acc = torch.zeros(self.shard, self.width, device=dev)
+        self.rccl = self.hip and dist.get_backend(group) == "nccl"
+        self._coalesce = self.rccl and not os.environ.get("G4S_OWNER_NO_COALESCE")
         self.last_rows_sent = None
 
     def _bounds(self, d):
@@ -162,21 +180,51 @@ class OwnerReduce:
         """`visible`: bool[P], the rows this rank's views can have touched (radii > 0, OR-ed over its views)."""
         # nonzero_static: fixed-size output (padded with P), so the host does not wait for the count here
         idx = torch.nonzero_static(visible, size=self.P, fill_value=self.P).view(-1)  # ascending => grouped by owner
-        owner = torch.div(idx, self.shard, rounding_mode="floor")
-        owner = torch.where(idx >= self.P, torch.full_like(owner, self.world), owner)  # the padding lands in bin `world`
-        counts = torch.zeros(self.world + 1, dtype=torch.int64, device=self.dev)
-        counts.scatter_add_(0, owner, torch.ones_like(owner))
-        counts = counts[:self.world].contiguous()
+        # per-owner counts: the list is sorted, so owner d's rows are the range between two binary searches (no atomics:
+        # a scatter_add of 1.5 M ones onto 8 counters would serialise on them)
+        pos = torch.searchsorted(idx, self._edges)
+        counts = (pos[1:] - pos[:-1]).contiguous()
         mat = torch.zeros(self.world, self.world, dtype=torch.int64, device=self.dev)
         dist.all_gather_into_tensor(mat.view(-1), counts, group=self.group)  # mat[src, dst]
         self._idx = idx
-        if self.dev.type == "cuda":
+        if self.hip:
             self._counts_host = torch.empty(mat.shape, dtype=mat.dtype, pin_memory=True)
             self._counts_host.copy_(mat, non_blocking=True)
             self._event = torch.cuda.Event()
             self._event.record()
         else:
             self._counts_host = mat.clone()
+
+    def _rows_kernel(self, idx, n, buf, mode):
+        """g4s_pack_rows over all row views: mode 2 = pack row-major, 7 = unpack row-major, adding (include/g4s_rasterizer.h)."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        k = len(self.rows)
+        ptrs = (ctypes.c_void_p * k)(*[r.data_ptr() for r in self.rows])
+        widths = (ctypes.c_int * k)(*self.widths)
+        with torch.cuda.device(self.dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            rc = lib.g4s_pack_rows(k, ptrs, widths, ctypes.c_void_p(idx.data_ptr()), int(n),
+                                   ctypes.c_void_p(buf.data_ptr()), int(mode), stream)
+        if rc != 0:
+            raise RuntimeError(f"g4s_pack_rows failed ({rc}): {_lib.last_error()}")
+
+    def _gather_in_place(self, lo, hi):
+        def issue():
+            for r in self.rows:
+                mine = r[lo:hi].reshape(-1)  # a view: rank d's rows of a contiguous [P, w] tensor are contiguous
+                # RCCL gathers in place when the input is the rank's own slot of the output; gloo wants them disjoint
+                dist.all_gather_into_tensor(r.view(-1), mine if self.rccl else mine.clone(), group=self.group)
+        if self._coalesce:
+            try:  # one RCCL group call for the per-tensor gathers
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
+                    issue()
+                return
+            except (ImportError, RuntimeError, TypeError, NotImplementedError):
+                self._coalesce = False  # this torch / backend cannot coalesce them: one collective per tensor
+        issue()
 
     def finish(self):
         """Reduces the rows in place: on return every row view holds the sum over all ranks."""
@@ -186,32 +234,48 @@ class OwnerReduce:
         mat = self._counts_host.tolist()
         send = [int(x) for x in mat[self.rank]]
         recv = [int(mat[s][self.rank]) for s in range(self.world)]
-        n = sum(send)
+        n, m = sum(send), sum(recv)
         idx = self._idx[:n]
         self.last_rows_sent = n - send[self.rank]
-        # pack my visible rows, [n, width] row-major
+        # pack my visible rows, [n, width] row-major: the rows for owner d are one contiguous range
         out_rows = torch.empty(n, self.width, device=self.dev)
-        off = 0
-        for r, w in zip(self.rows, self.widths):
-            out_rows[:, off:off + w] = r.index_select(0, idx)
-            off += w
-        in_rows = torch.empty(sum(recv), self.width, device=self.dev)
-        in_idx = torch.empty(sum(recv), dtype=torch.int64, device=self.dev)
+        if self.hip:
+            if n:
+                self._rows_kernel(idx, n, out_rows, 2)
+        else:
+            off = 0
+            for r, w in zip(self.rows, self.widths):
+                out_rows[:, off:off + w] = r.index_select(0, idx)
+                off += w
+        in_rows = torch.empty(m, self.width, device=self.dev)
+        in_idx = torch.empty(m, dtype=torch.int64, device=self.dev)
         dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
         dist.all_to_all_single(in_idx, idx.contiguous(), recv, send, group=self.group)
-        # owner: sum what arrived, source by source (a source contributes a row at most once => no duplicate
-        # indices inside one index_add_, and the order of the additions is fixed)
-        lo, hi = self._bounds(self.rank)
-        acc = torch.zeros(self.shard, self.width, device=self.dev)
+        # owner: my own contribution already sits in my slice; add the other ranks' rows to it, source by source (a
+        # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
         o = 0
         for s in range(self.world):
             c = recv[s]
-            if c:
-                acc.index_add_(0, in_idx[o:o + c] - lo, in_rows[o:o + c])
+            if c and s != self.rank:
+                if self.hip:
+                    self._rows_kernel(in_idx[o:o + c], c, in_rows[o:o + c], 7)
+                else:
+                    off = 0
+                    for r, w in zip(self.rows, self.widths):
+                        r.index_add_(0, in_idx[o:o + c], in_rows[o:o + c, off:off + w])
+                        off += w
             o += c
         # every rank gets every reduced shard
-        dist.all_gather_into_tensor(self._gather.view(-1), acc.view(-1), group=self.group)
-        full = self._gather[:self.P] if self.world * self.shard != self.P else self._gather
+        lo, hi = self._bounds(self.rank)
+        if self.even:
+            self._gather_in_place(lo, hi)
+            return
+        off = 0
+        for r, w in zip(self.rows, self.widths):
+            self._acc[:hi - lo, off:off + w] = r[lo:hi]
+            off += w
+        dist.all_gather_into_tensor(self._gather.view(-1), self._acc.view(-1), group=self.group)
+        full = self._gather[:self.P]
         # (shards are padded to `shard` rows: rank d's rows sit at [d * shard, d * shard + (hi_d - lo_d)) = their global index)
         off = 0
         for r, w in zip(self.rows, self.widths):

@@ -225,12 +225,15 @@ int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
 /*
  * Row packing for the multi-GPU gradient exchange (new functionality; no reference
  * counterpart): gathers the rows `row_index[0..n)` of up to 8 row-major float segments
- * (segment s = [P, widths[s]]) into one contiguous buffer, segment after segment
- * (packed = [n*widths[0] | n*widths[1] | ...]), or scatters such a buffer back (`unpack` != 0).
+ * (segment s = [P, widths[s]]) into one contiguous buffer, or scatters such a buffer back.  `mode`:
+ *   bit 0   0 = pack (rows -> buffer), 1 = unpack (buffer -> rows)
+ *   bit 1   buffer layout: 0 = segment after segment (packed = [n*widths[0] | n*widths[1] | ...]),
+ *           1 = row-major [n, sum(widths)] (row ranges of the buffer are contiguous: all_to_all splits)
+ *   bit 2   unpack adds to the rows instead of overwriting them (indices must be distinct)
  * `segments` / `widths` are HOST arrays of device pointers / ints; `row_index` is a device int64 array.
  */
 int g4s_pack_rows(int nseg, float* const* segments, const int* widths, const long long* row_index, int n,
-                  float* packed, int unpack, void* stream);
+                  float* packed, int mode, void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py
  * for the roofline figure; off by default, process-wide).  Kernel groups 0..g4s_profile_kernels()-1

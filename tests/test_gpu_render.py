@@ -170,6 +170,25 @@ def test_pack_rows_roundtrip(hip_lib):
     for s, b in zip(segs, before):
         assert torch.equal(s[idx], 2.0 * b[idx]) and torch.equal(s[keep], b[keep])
     assert hip_lib.g4s_pack_rows(9, ptrs, wid, None, 0, None, 0, stream) < 0
+    # row-major buffer [n, sum w] (mode bit 1) and accumulating unpack (bit 2): what OwnerReduce moves through all_to_all
+    rm = torch.full((n, sum(widths)), float("nan"), device="cuda:0")
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(rm.data_ptr()), 2, stream) == 0
+    assert torch.equal(rm, torch.cat([s.index_select(0, idx) for s in segs], dim=1))
+    before = [s.clone() for s in segs]
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(rm.data_ptr()), 7, stream) == 0
+    torch.cuda.synchronize()
+    for s, b in zip(segs, before):
+        assert torch.equal(s[idx], b[idx] + b[idx]) and torch.equal(s[keep], b[keep])
+    rm.fill_(1.5)
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(rm.data_ptr()), 3, stream) == 0
+    torch.cuda.synchronize()
+    for s, b in zip(segs, before):
+        assert bool((s[idx] == 1.5).all()) and torch.equal(s[keep], b[keep])
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(rm.data_ptr()), 4, stream) < 0  # add without unpack
 
 
 @pytest.mark.parametrize("D,M", [(3, 16), (1, 16), (0, 16), (2, 9), (0, 1)])
