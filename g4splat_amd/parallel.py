@@ -234,9 +234,14 @@ class OwnerReduce:
         mat = self._counts_host.tolist()
         send = [int(x) for x in mat[self.rank]]
         recv = [int(mat[s][self.rank]) for s in range(self.world)]
+        # rows this rank owns itself stay where they are: they are neither packed nor sent
+        a = sum(send[:self.rank])
+        b = a + send[self.rank]
+        self.last_rows_sent = sum(send) - send[self.rank]
+        idx = torch.cat((self._idx[:a], self._idx[b:sum(send)]))
+        send[self.rank] = 0
+        recv[self.rank] = 0
         n, m = sum(send), sum(recv)
-        idx = self._idx[:n]
-        self.last_rows_sent = n - send[self.rank]
         # pack my visible rows, [n, width] row-major: the rows for owner d are one contiguous range
         out_rows = torch.empty(n, self.width, device=self.dev)
         if self.hip:
@@ -250,13 +255,13 @@ class OwnerReduce:
         in_rows = torch.empty(m, self.width, device=self.dev)
         in_idx = torch.empty(m, dtype=torch.int64, device=self.dev)
         dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
-        dist.all_to_all_single(in_idx, idx.contiguous(), recv, send, group=self.group)
+        dist.all_to_all_single(in_idx, idx, recv, send, group=self.group)
         # owner: my own contribution already sits in my slice; add the other ranks' rows to it, source by source (a
         # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
         o = 0
         for s in range(self.world):
             c = recv[s]
-            if c and s != self.rank:
+            if c:
                 if self.hip:
                     self._rows_kernel(in_idx[o:o + c], c, in_rows[o:o + c], 7)
                 else:
