@@ -239,7 +239,6 @@ void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
 // K7 backward
 
 constexpr int BWD_BATCH = 64;
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct BwdPixel {
     // constants.  The distortion terms only ever appear multiplied by dL_dreg, so they are kept as
@@ -375,14 +374,17 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
             const bool nolp = (nolp_mask >> j) & 1ull;                               // scalar
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-            // the 18 accumulators live in nine aligned register pairs so that they are zeroed with nine v_mov_b64;
-            // the zero is pinned here: left alone, the compiler sinks the initialisation into both arms of the first
-            // quadrant's branch and joins them with a 16-deep copy chain (33 moves)
-            v2f gp[9];
+            // the 18 accumulators are plain floats zeroed one by one, and the zero is pinned here: left alone, the
+            // compiler sinks the initialisation into both arms of the first quadrant's branch and joins them with a
+            // 16-deep copy chain (33 moves).  (Nine 64-bit register pairs zeroed with v_mov_b64 looked cheaper but every
+            // half had to be copied out again in front of the permlane swaps of the reduction: 9 + 15 moves instead of 18.)
+            struct F2 { float x, y; };
+            F2 gp[9];
 #pragma unroll
             for (int i = 0; i < 9; i++) {
-                gp[i] = v2f{0.0f, 0.0f};
-                asm volatile("" : "+v"(gp[i]));
+                gp[i].x = 0.0f;
+                gp[i].y = 0.0f;
+                asm volatile("" : "+v"(gp[i].x), "+v"(gp[i].y));
             }
             bool lowpass = false;
 #pragma unroll
