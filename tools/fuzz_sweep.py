@@ -73,7 +73,7 @@ for seed in range(first, first + count):
             if not cot and not os.environ.get("FUZZ_CONTRACT_BARS"):
                 # default criterion: the test suite's -- guard bars (~10x the measured error) on everything that is not
                 # explained by a decision threshold within 1e-5 of its value in the oracle (tests/common.py)
-                assert_parity(h, o, inp, oracle_mod, tag=tag)
+                assert_parity(h, o, inp, oracle_mod, tag=tag, scale_aware=scene_scale != 1.0)
                 if o["R"] > 0 and mode == "policy":
                     check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
                 continue
@@ -99,7 +99,10 @@ for seed in range(first, first + count):
                     # (distortion of one or two splats, median depth w.r.t. scales: exactly zero in exact arithmetic --
                     # what is left is the random walk of ~H W roundings of O(|cotangent|) terms)
                     floor = 1e-7 * np.sqrt(H * W) * max(float(np.abs(g[0]).max()), float(np.abs(g[1]).max()))
-                    assert d <= GRAD_RTOL * float(np.abs(o["grads"][name]).max()) + 1e-4 * S + floor, "grad " + name
+                    # scale / rotation gradients are dL_dT pushed through the projection (entries ~ the focal length in
+                    # pixels): for hair-thin splats (scale 1e-5) the true value is a difference of terms ~ S * focal
+                    cond = 4e-6 * S * max(W, H) if name in ("scales", "rotations") else 0.0
+                    assert d <= GRAD_RTOL * float(np.abs(o["grads"][name]).max()) + 1e-4 * S + floor + cond, "grad " + name
                     continue
                 assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, "grad " + name
         except AssertionError as ex:
