@@ -548,7 +548,7 @@ static int rasterizer_backward_impl(
             float* zb[2] = {dL_dsh, dL_dsh_rest};
             const size_t zn[2] = {(size_t)P * (dL_dsh_rest ? 1 : M) * 3, dL_dsh_rest ? (size_t)P * (M - 1) * 3 : 0};
             bool ok = true;
-            for (int z = 0; z < 2; z++) ok = ok && (zn[z] == 0 || (!misaligned(zb[z], 16) && (zn[z] >> 2) <= 0xffffffffull));
+            for (int z = 0; z < 2; z++) ok = ok && (zn[z] == 0 || (!misaligned(zb[z], 16) && (zn[z] >> 2) < 0x80000000ull));  // (the kernel's u32 loop index must not wrap)
             if (ok) {
                 for (int z = 0; z < 2; z++) {
                     if (zn[z] == 0) continue;
