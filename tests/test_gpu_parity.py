@@ -664,6 +664,21 @@ def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P, monkeypa
             else:
                 assert dsh.data_ptr() == out["dL_dsh"].data_ptr()
             results[(side, split)] = dsh.cpu().numpy()
+    # an output view that is only 4-byte aligned: no 16-byte stores anywhere, K8 clears the rows itself
+    monkeypatch.delenv("G4S_NO_SIDE_ZERO", raising=False)
+    fw = _C.rasterize_gaussians(a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"], a["rotations"], 1.0,
+                                a["transMat"], a["view"], a["proj"], inp["tanfovx"], inp["tanfovy"], inp["H"], inp["W"],
+                                a["sh"], inp["D"], a["campos"], False, False)
+    R, color, others, radii, geom, binning, img = fw
+    pool = torch.full((P * 48 + 8,), float("nan"), device="cuda:0")
+    odd = pool[1:1 + P * 48].view(P, 16, 3)
+    assert odd.data_ptr() % 16 == 4
+    g = _C.rasterize_gaussians_backward(a["bg"], a["means3D"], radii, a["colors"], a["scales"], a["rotations"], 1.0,
+                                        a["transMat"], a["view"], a["proj"], inp["tanfovx"], inp["tanfovy"], t(gr[0]),
+                                        t(gr[1]), a["sh"], inp["D"], a["campos"], geom, R, binning, img, False,
+                                        out={"dL_dsh": odd})
+    results[("misaligned", False)] = g[5].cpu().numpy()
+    assert bool(torch.isnan(pool[:1]).all()) and bool(torch.isnan(pool[1 + P * 48:]).all())  # nothing written outside the view
     for key, v in results.items():
         assert not np.isnan(v).any(), key
         assert np.array_equal(v, base["grads"]["sh"]), key
