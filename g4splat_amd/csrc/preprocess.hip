@@ -598,9 +598,9 @@ constexpr int K8_OUT_MEAN2D = 0, K8_OUT_NORMAL = 768, K8_OUT_OPACITY = 1536, K8_
 // (0.169 ms for 0.44 GB).  Summation order: fixed (per lane ascending record index, then the DPP tree), so the
 // gradients stay bit-reproducible.
 //
-// The kernel also clears the dL_dsh rows of the Gaussians preprocess_bwd will not write (radii == 0) -- 72 % of a
-// 288 MB tensor at S3 -- with coalesced stores that overlap its own latency-bound gather; that used to be a separate
-// 0.038 ms memset.
+// Unless the blend backward has cleared dL_dsh on the side (PreprocessBwdArgs::sh_prezeroed, frames that run the
+// one-wave kernel), the fold phase also clears the dL_dsh rows of the Gaussians phase 2 will not write (radii == 0) -- 72 %
+// of a 288 MB tensor at S3 -- with coalesced stores that overlap its own latency-bound gather.
 struct FoldShZero {
     float* base;      // dL_dsh (or its [P,M-1,3] rest part); NULL = nothing to clear
     int row_floats;   // floats per Gaussian
@@ -929,7 +929,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         dmean2[0] = (float)(dT_out[2] * depth_T8 * 0.5 * (float)a.W);
         dmean2[1] = (float)(dT_out[5] * depth_T8 * 0.5 * (float)a.H);
     }
-    // rows of dL_dsh that belong to invisible Gaussians were cleared by fold_records_kernel (coalesced, block-wide)
+    // (rows of dL_dsh that belong to invisible Gaussians: cleared by the fold phase above or beside the blend backward)
 
     // Outputs: every thread parks its 28 floats in LDS, then the block writes each tensor's 256-row region with
     // coalesced 16-byte stores -- 7 store instructions per thread instead of 28 strided dword stores, three quarters of
@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
-    // dL_dsh rows of the Gaussians phase 2 does not write are cleared by the fold phase (no separate memset)
+    // dL_dsh rows of the Gaussians phase 2 does not write: cleared by the fold phase unless the blend backward did it
     FoldShZero z0{nullptr, 0}, z1{nullptr, 0};
     if (a.M > 0 && a.dL_dsh != nullptr && !a.sh_prezeroed) {
         if (a.shs_rest != nullptr) {
