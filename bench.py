@@ -153,6 +153,7 @@ def main():
         row_views = [v.view(P, -1) for v in grad_out.values()] + [side]
         reducer = OwnerReduce(row_views) if exchange == "owner" else RowSparseAllReduce(bucket, row_views)
     exchanged_rows = []
+    exchange_events = None  # list of (start, stop) events while the instrumented pass runs
 
     pstate = None
 
@@ -175,6 +176,10 @@ def main():
                                                 dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
                                                 img, False, out=grad_out)
         if dist is not None:
+            ev = None
+            if exchange_events is not None:  # instrumented pass only: GPU time of the exchange, this rank
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             gm2 = grads[0]
             torch.linalg.vector_norm(gm2[:, :2], dim=1, out=side[:, 0])
             side[:, 1] = radii > 0
@@ -186,6 +191,9 @@ def main():
             else:
                 reducer.reduce(rmax > 0)
                 exchanged_rows.append(reducer.last_rows)
+            if ev is not None:
+                ev[1].record()
+                exchange_events.append(ev)
         return R, radii
 
     # warm-up (also measures V and R per view outside the timed region)
@@ -251,7 +259,15 @@ def main():
         return dt
 
     elapsed = timed_steps(False)            # the headline: value / ms_per_step
-    elapsed_events = timed_steps(True) if timing else None   # same steps again, instrumented: kernels_ms / roofline
+    exchange_ms = None
+    if timing:                              # same steps again, instrumented: kernels_ms / roofline (+ the exchange at N > 1)
+        exchange_events = [] if dist is not None else None
+        elapsed_events = timed_steps(True)
+        if exchange_events:
+            exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / len(exchange_events)
+        exchange_events = None
+    else:
+        elapsed_events = None
 
     units = sum(Vs[(rank + i * world) % len(dcams)] for i in range(args.steps))
     inst = sum(Rs[(rank + i * world) % len(dcams)] for i in range(args.steps))
@@ -346,7 +362,10 @@ def main():
                                                                    ("-owner-reduce(all_to_all+all_gather)" if exchange == "owner"
                                                                     else "-visible-rows-" + exchange)) if world > 1 else ""),
                    "exchanged_rows_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows
-                                               else None)},
+                                               else None),
+                   # GPU time of the gradient exchange per step on rank 0 (statistics + radii MAX + owner-reduce), from the
+                   # instrumented pass; it is part of every timed step at N > 1
+                   "exchange_ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None},
         "gaussians_total_per_s": P * args.steps * world / elapsed,
         "instances_per_s": inst / elapsed,
         "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},
