@@ -683,3 +683,53 @@ def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P, monkeypa
         assert not np.isnan(v).any(), key
         assert np.array_equal(v, base["grads"]["sh"]), key
         assert np.all(v[base["radii"] == 0] == 0), key
+
+
+def test_presized_step_replays_from_a_hip_graph(hip_lib):
+    """nothing in g4s_rasterizer_forward_presized + g4s_rasterizer_backward touches the host, so
+    the pair can be captured in a HIP graph (torch.cuda.CUDAGraph) with the camera in static buffers.  Replays for two
+    different views are bit-identical to the eager calls."""
+    import torch
+    from g4splat_amd.diff_surfel_rasterization import _C
+    inp = scene_inputs(P=30000, W=640, H=480, seed=31, D=3, bg=(0.3, 0.2, 0.1))
+    gr = cotangents(480, 640, seed=9)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda:0")
+    a = dict((k, t(v)) for k, v in inp.items() if isinstance(v, np.ndarray))
+    # second view: the first camera moved (same intrinsics: tan_fov, W, H are baked into the captured launches)
+    shift = torch.eye(4, device="cuda:0")
+    shift[3, 0], shift[3, 2] = 0.15, 0.1
+    view2 = a["view"] @ shift
+    cams = [(a["view"], a["proj"], a["campos"]),
+            (view2, view2 @ (torch.linalg.inv(a["view"]) @ a["proj"]), torch.linalg.inv(view2)[3, :3].contiguous())]
+    view_s, proj_s, campos_s = (x.clone() for x in cams[0])
+    g0, g1 = t(gr[0]), t(gr[1])
+
+    def fwd_bwd(state, view, proj, campos):
+        fw = _C.rasterize_gaussians_presized(state, a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"],
+                                             a["rotations"], 1.0, a["transMat"], view, proj, inp["tanfovx"], inp["tanfovy"],
+                                             inp["H"], inp["W"], a["sh"], inp["D"], campos, False, False)
+        cap, color, others, radii, geom, binning, img = fw
+        g = _C.rasterize_gaussians_backward(a["bg"], a["means3D"], radii, a["colors"], a["scales"], a["rotations"], 1.0,
+                                            a["transMat"], view, proj, inp["tanfovx"], inp["tanfovy"], g0, g1, a["sh"],
+                                            inp["D"], campos, geom, cap, binning, img, False)
+        return [color, others, radii] + [x for x in g if x.numel()]
+
+    R0 = run_hip(inp)["R"]
+    state = _C.PresizedState(30000, 640, 480, int(R0 * 2) + 4096, "cuda:0")
+    eager = [[x.clone() for x in fwd_bwd(state, *c)] for c in cams]
+    assert not torch.equal(eager[0][0], eager[1][0])  # the two views differ
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd_bwd(state, view_s, proj_s, campos_s)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = fwd_bwd(state, view_s, proj_s, campos_s)
+    for k in (1, 0, 1):
+        view_s.copy_(cams[k][0]); proj_s.copy_(cams[k][1]); campos_s.copy_(cams[k][2])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert state.status.tolist()[3] == 0
+        for got, want in zip(outs, eager[k]):
+            assert torch.equal(got, want), k
