@@ -695,7 +695,7 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
             if (lane == 0) { dst[16] = sB.x; dst[17] = sB.y; }
         }
         uint64_t vis = __ballot(my_cnt != 0 && my_cnt <= FOLD_ROW_MAX);
-        constexpr int U = 2;  // groups of four Gaussians in flight
+        constexpr int U = 3;  // groups of four Gaussians in flight
         while (vis) {
             // group u, row r folds the (4 u + r)-th remaining member of the wave that has records
             int jj[U];
