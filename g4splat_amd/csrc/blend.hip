@@ -325,6 +325,9 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
     const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m = mscale - dmd_k / depth, dm/ddepth = dmd_k / depth^2
     const bool row_writer = (lane & 15) == 15;
     const int row = lane >> 4;
+    // the reduction of an entry's sixteen common terms leaves term 4 row + quad_term(lane) in every lane of a quad
+    const bool lane_b3 = (lane & 8) != 0, lane_b2 = (lane & 4) != 0, quad_writer = (lane & 3) == 0;
+    const int term_of_lane = 4 * row + quad_term(lane);
 
     // list positions >= the tile's max last_contributor cannot contribute anywhere
     const int n_live = (int)wave_max_u32(max_last);
@@ -482,9 +485,8 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                 float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
                 float t[16] = {gp[0].x, gp[0].y, gp[1].x,  gp[1].y,  gp[2].x,  gp[2].y,  gp[3].x,  gp[3].y,
                                gp[4].x, gp[4].y, gp[5].x, gp[5].y, gp[6].x, gp[6].y, gp[7].x, gp[8].y};
-                float r[4];
-                wave_sum16_to_rows(t, r);
-                if (row_writer) *reinterpret_cast<float4*>(rec + 4 * row) = make_float4(r[0], r[1], r[2], r[3]);
+                const float y = wave_sum16_to_quads(t, lane_b3, lane_b2);
+                if (quad_writer) rec[term_of_lane] = y;  // sixteen lanes, sixteen consecutive floats
                 const bool lp = __any(lowpass);
                 if (lp) {
                     const float r4 = wave_sum4_to_rows(gp[7].y, gp[8].x, 0.0f, 0.0f);

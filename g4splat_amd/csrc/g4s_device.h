@@ -114,6 +114,50 @@ __device__ __forceinline__ void wave_sum16_to_rows(float (&v)[16], float (&out)[
     out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3;
 }
 
+// The same sixteen sums, one value per lane: the lane's 4-lane quad q = (lane >> 2) & 3 of row k = lane >> 4 ends up with
+// the wave sum of v[4k + 2 (q & 1) + (q >> 1)]  (see quad_term()).  After the swap stages the four registers are folded
+// into one while they are reduced: lanes whose bit 3 is set keep r1 / r3 and hand r0 / r2 to the lane eight further (and
+// vice versa), then bit 2 decides between the two survivors through a half-row mirror (which pairs the quads of a half
+// row; it also reverses the lanes inside them, which the last two steps -- a sum over the quad -- do not care about).
+// 11 DPP-class instructions instead of the 16 of four parallel butterflies.  `b3` / `b2` = (lane & 8) != 0 / (lane & 4)
+// != 0, computed once by the caller so that they live in scalar registers.
+__host__ __device__ __forceinline__ int quad_term(int lane) { return 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1); }
+__device__ __forceinline__ float wave_sum16_to_quads(float (&v)[16], bool b3, bool b2) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\t"
+        "v_permlane32_swap_b32 %1, %9\n\t"
+        "v_permlane32_swap_b32 %2, %10\n\t"
+        "v_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\t"
+        "v_permlane32_swap_b32 %5, %13\n\t"
+        "v_permlane32_swap_b32 %6, %14\n\t"
+        "v_permlane32_swap_b32 %7, %15"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+    float s0 = v[0] + v[8], s1 = v[1] + v[9], s2 = v[2] + v[10], s3 = v[3] + v[11];
+    float s4 = v[4] + v[12], s5 = v[5] + v[13], s6 = v[6] + v[14], s7 = v[7] + v[15];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %4\n\t"
+        "v_permlane16_swap_b32 %1, %5\n\t"
+        "v_permlane16_swap_b32 %2, %6\n\t"
+        "v_permlane16_swap_b32 %3, %7"
+        : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7));
+    // rows 0..3 of r_i: partial sums of v[i], v[4+i], v[8+i], v[12+i]
+    const float r0 = s0 + s4, r1 = s1 + s5, r2 = s2 + s6, r3 = s3 + s7;
+    const float k01 = b3 ? r1 : r0, g01 = b3 ? r0 : r1;
+    const float k23 = b3 ? r3 : r2, g23 = b3 ? r2 : r3;
+    const float x01 = k01 + dpp_f32<0x128>(g01);  // row_ror:8 : lane l <-> l ^ 8
+    const float x23 = k23 + dpp_f32<0x128>(g23);
+    const float k = b2 ? x23 : x01, g = b2 ? x01 : x23;
+    float y = k + dpp_f32<0x141>(g);              // row_half_mirror: the other quad of the same half row
+    y += dpp_f32<0xB1>(y);                        // quad_perm:[1,0,3,2]
+    y += dpp_f32<0x4E>(y);                        // quad_perm:[2,3,0,1]
+    asm volatile("" : "+v"(y));                   // (keep the last additions out of the caller's store branch)
+    return y;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_sum_to_lane63(v), 63);
 }

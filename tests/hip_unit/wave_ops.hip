@@ -16,6 +16,12 @@ __global__ void k_sum16(const float* in, float* out) {
     wave_sum16_to_rows(v, r);
     for (int i = 0; i < 4; i++) out[i * 64 + l] = r[i];
 }
+__global__ void k_sum16q(const float* in, float* out) {
+    const int l = threadIdx.x;
+    float v[16];
+    for (int t = 0; t < 16; t++) v[t] = in[t * 64 + l];
+    out[l] = wave_sum16_to_quads(v, (l & 8) != 0, (l & 4) != 0);
+}
 __global__ void k_sum63(const float* in, float* out) { out[threadIdx.x] = wave_sum_to_lane63(in[threadIdx.x]); }
 __global__ void k_swap32(const float* in, float* out) { out[threadIdx.x] = swap32_sum(in[threadIdx.x], in[64 + threadIdx.x]); }
 __global__ void k_swap16(const float* in, float* out) { out[threadIdx.x] = swap16_sum(in[threadIdx.x], in[64 + threadIdx.x]); }
@@ -54,6 +60,13 @@ int main() {
         for (int i = 0; i < 4; i++) for (int l = 0; l < 64; l++) {
             const float w = (float)w16[4 * (l >> 4) + i];
             if (o16[i * 64 + l] != w) { bad++; if (bad < 32) printf("sum16 out[%d] lane %d got %f want %f\n", i, l, o16[i * 64 + l], w); }
+        }
+        // one value per lane: quad q of row k holds term 4k + quad_term
+        hipLaunchKernelGGL(k_sum16q, dim3(1), dim3(64), 0, 0, d16, o16d);
+        hipMemcpy(o16.data(), o16d, 256, hipMemcpyDeviceToHost);
+        for (int l = 0; l < 64; l++) {
+            const float w = (float)w16[4 * (l >> 4) + quad_term(l)];
+            if (o16[l] != w) { bad++; if (bad < 40) printf("sum16q lane %d got %f want %f\n", l, o16[l], w); }
         }
     }
     printf(bad ? "FAILED (%d)\n" : "wave_ops OK\n", bad);
