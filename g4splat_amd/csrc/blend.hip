@@ -254,7 +254,7 @@ struct BwdPixel {
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// Occupancy is what this kernel responds to: at 158 VGPRs three waves fit a SIMD, at <= 128 four
+// Occupancy is what this kernel responds to (LAB_NOTES.md): at 158 VGPRs three waves fit a SIMD, at <= 128 four
 // do.  Of the 20 per-pixel values a lane carries for each of its four pixels, six are read once per visit (or
 // less) and never written: the three distortion constants, the background term, the median position and its
 // cotangent.  They are parked in LDS (24 B per pixel, read back with one ds_read_b128 per visit plus one
