@@ -67,3 +67,28 @@ def test_owner_reduce_device_path_with_two_ranks_on_one_gpu():
             assert 0 <= sent <= nvis
             if frac == 0.3:
                 assert 0.3 * nvis < sent < 0.7 * nvis  # about half of a rank's visible rows belong to the other owner
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """bench.py's N > 1 path end to end (launcher, warm-up fallback logic, owner-reduce exchange inside the timed steps,
+    max-over-ranks timing, the one JSON line) with two gloo ranks sharing cuda:0 -- the bring-up mode bench.py documents
+    (G4S_BENCH_BACKEND / G4S_BENCH_ONE_DEVICE).  The numbers of such a run mean nothing; the control flow is what the
+    driver's multi-GPU run will execute."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, G4S_BENCH_BACKEND="gloo", G4S_BENCH_ONE_DEVICE="1")
+    port = 36500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "s2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert "owner-reduce" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert d["config"]["exchanged_rows_per_step"] > 0
+    assert d["config"]["exchange_ms_per_step"] > 0
+    assert d["cpu_baseline"] is None and d["roofline"] is not None
