@@ -283,6 +283,7 @@ static int rasterizer_forward_impl(
         pa.shs_rest = shs_rest;
         pa.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16));
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
+        pa.tight_rect = (uint2*)(geom + GL.tight_rect);
         pa.depth_keys = keys_a;
         pa.ref_block_sums = (uint32_t*)(geom + GL.ref_block_sums);
         pa.idx_block_sums = (uint32_t*)(geom + GL.idx_block_sums);
@@ -375,8 +376,9 @@ static int rasterizer_forward_impl(
         qhit_ptr = (uint8_t*)(bin + BL.qhit);
         if (R_binned > 0) {
             { ProfScope ps(PF_EMIT, stream);  // (also clears the contribution masks qhit[0, R_binned))
-              launch_emit(V_emit, (uint32_t)R_binned, tiles_x, tiles_y, gidx_sorted, block_offs, nblocks_v, rank_local,
-                          radii, rec, ent_a, qhit_ptr, (uint8_t*)(bin + BL.rec_flag), stream, d_counts); }
+              launch_emit(V_emit, (uint32_t)R_binned, tiles_x, gidx_sorted, block_offs, nblocks_v, rank_local,
+                          (const uint2*)(geom + GL.tight_rect), ent_a, qhit_ptr, (uint8_t*)(bin + BL.rec_flag), stream,
+                          d_counts); }
             CHECK_LAUNCH("emit");
             const int tile_bits = tile_sort_bits(tiles);  // rasterizer_impl.cu:301
             int c2;

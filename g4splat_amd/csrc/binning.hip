@@ -336,11 +336,11 @@ constexpr int EMIT_SLOTS = 1024;
 // d_counts != NULL (g4s_rasterizer_forward_presized: the host never learns the counts): V = d_counts[0] emitting
 // Gaussians, R_b = d_counts[1] instances (already clamped to the caller's capacity); the grid is sized for the
 // capacity and surplus blocks leave.
-__global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tiles_x, int tiles_y,
+__global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tiles_x,
                                                    const uint32_t* __restrict__ gidx,
                                                    const uint32_t* __restrict__ block_offs, int nblocks_v,
                                                    const uint32_t* __restrict__ rank_local,
-                                                   const int* __restrict__ radii, const float* __restrict__ rec,
+                                                   const uint2* __restrict__ tight_rect,
                                                    uint64_t* __restrict__ entries, uint8_t* __restrict__ qhit,
                                                    uint8_t* __restrict__ rec_flag,
                                                    const uint32_t* __restrict__ d_counts) {
@@ -394,15 +394,11 @@ __global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tile
         const uint32_t off = block_offs[r >> 8] + rank_local[r];
         if (off >= w1) break;  // offsets ascend with the rank: nothing further on for this thread either
         const uint32_t idx = gidx[r];
-        const float4* rq = reinterpret_cast<const float4*>(rec) + (size_t)idx * REC_QUADS;
-        const float4 q0 = rq[0], q5 = rq[5];
-        int rx0, ry0, rx1, ry1, x0, y0, x1, y1;
-        get_rect(q0.x, q0.y, radii[idx], tiles_x, tiles_y, rx0, ry0, rx1, ry1);
-        tight_tile_rect(q5, rx0, ry0, rx1, ry1, x0, y0, x1, y1);  // same arithmetic as the preprocess
+        const uint2 tr = tight_rect[idx];  // the rect the preprocess counted (x0 | y0 << 16, width)
         s_off[i] = off;
         s_idx[i] = idx;
-        s_rect[i] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-        s_rect2[i] = (uint32_t)(x1 - x0);
+        s_rect[i] = tr.x;
+        s_rect2[i] = tr.y;
         atomicMax(&s_nr, (uint32_t)i + 1u);
     }
     __syncthreads();
@@ -468,12 +464,12 @@ void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs
                        (const uint32_t*)nullptr, capacity, host_out, status_out);
 }
 
-void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
-                 int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
+void launch_emit(int V, uint32_t R_b, int tiles_x, const uint32_t* gidx_sorted, const uint32_t* block_offs,
+                 int nblocks_v, const uint32_t* rank_local, const uint2* tight_rect, uint64_t* entries,
                  uint8_t* qhit, uint8_t* rec_flag, hipStream_t s, const uint32_t* d_counts) {
     if (R_b == 0) return;  // (d_counts != NULL: R_b is the capacity the grid is sized for)
-    hipLaunchKernelGGL(emit_kernel, dim3((R_b + EMIT_SLOTS - 1) / EMIT_SLOTS), dim3(256), 0, s, V, R_b, tiles_x, tiles_y,
-                       gidx_sorted, block_offs, nblocks_v, rank_local, radii, rec, entries, qhit, rec_flag, d_counts);
+    hipLaunchKernelGGL(emit_kernel, dim3((R_b + EMIT_SLOTS - 1) / EMIT_SLOTS), dim3(256), 0, s, V, R_b, tiles_x,
+                       gidx_sorted, block_offs, nblocks_v, rank_local, tight_rect, entries, qhit, rec_flag, d_counts);
 }
 
 // rasterizer_impl.cu:116-138 on the packed entries (ranges pre-zeroed, :311).  Four consecutive entries per thread

@@ -48,7 +48,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // Sub-allocation of the three caller-owned chunks.  Private between forward and backward
 // (the reference's GeometryState/BinningState/ImageState, rasterizer_impl.h:21-73).
 struct GeomLayout {
-    size_t rec, clamped, tiles_touched, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
+    size_t rec, clamped, tiles_touched, tight_rect, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
         block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, vis_block_sums, vis_block_offs, total, bytes;
     int nblocks;   // 256-wide blocks over P
 };
@@ -67,6 +67,7 @@ inline GeomLayout geom_layout(size_t P) {
     L.rec = take(P * REC_FLOATS * 4);
     L.clamped = take(P);
     L.tiles_touched = take(P * 4);
+    L.tight_rect = take(P * 8);  // (x0 | y0 << 16, width) of the tile rect the Gaussian is binned into; written where tiles_touched > 0
     L.internal_radii = take(P * 4);
     L.keys_a = take(P * 4);
     L.keys_b = take(P * 4);
@@ -131,6 +132,7 @@ struct PreprocessArgs {
     float* rec;
     uint8_t* clamped;
     uint32_t* tiles_touched;
+    uint2* tight_rect;  // (x0 | y0 << 16, width in tiles) of the rect counted in tiles_touched; written where that is > 0
     int* radii;
     uint32_t* depth_keys;
 };
@@ -164,9 +166,9 @@ void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32
                               const uint32_t* depth_keys, const uint32_t* vis_block_offs, uint32_t* keys_out,
                               uint32_t* idx_out, int nblocks, hipStream_t s);
 // Instances in depth order, R_b of them; also clears qhit[0, R_b) and rec_flag[0, R_b).
-void launch_emit(int V, uint32_t R_b, int tiles_x, int tiles_y, const uint32_t* gidx_sorted, const uint32_t* block_offs,
-                 int nblocks_v, const uint32_t* rank_local, const int* radii, const float* rec, uint64_t* entries,
-                 uint8_t* qhit, uint8_t* rec_flag, hipStream_t s, const uint32_t* d_counts = nullptr);
+void launch_emit(int V, uint32_t R_b, int tiles_x, const uint32_t* gidx_sorted, const uint32_t* block_offs,
+                 int nblocks_v, const uint32_t* rank_local, const uint2* tight_rect, uint64_t* entries,
+                 uint8_t* qhit, uint8_t* rec_flag, hipStream_t s, const uint32_t* d_counts);
 void launch_tile_ranges(int R, const uint64_t* entries, uint32_t* ranges, hipStream_t s, const uint32_t* d_n = nullptr);
 // Longest-list-first processing order of the tiles (work balance of the blend kernels).
 void launch_tile_order(int tiles, const uint32_t* ranges, uint32_t* tile_order, hipStream_t s, uint32_t* zero_word = nullptr);

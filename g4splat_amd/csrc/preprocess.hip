@@ -369,6 +369,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         int tx0, ty0, tx1, ty1;
                         tight_tile_rect(box, x0, y0, x1, y1, tx0, ty0, tx1, ty1);
                         touched = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
+                        // the emit kernel expands exactly this rect: 8 bytes per Gaussian instead of two record quads + radius
+                        if (touched != 0) a.tight_rect[idx] = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)(tx1 - tx0));
                         rec[0] = cx;
                         rec[1] = cy;
                         rec[3] = __uint_as_float(touched | (lowpass_never_matters(T, cx, cy, opa) ? REC_NO_LOWPASS : 0u));
