@@ -222,8 +222,10 @@ class OwnerReduce:
                 with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
                     issue()
                 return
-            except (ImportError, RuntimeError, TypeError, NotImplementedError):
+            except (ImportError, RuntimeError, TypeError, NotImplementedError) as ex:
                 self._coalesce = False  # this torch / backend cannot coalesce them: one collective per tensor
+                import warnings
+                warnings.warn(f"OwnerReduce: coalesced in-place all_gather unavailable ({ex}); issuing one collective per tensor")
         issue()
 
     def finish(self):
