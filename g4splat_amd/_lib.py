@@ -46,6 +46,8 @@ SIGNATURES = {
     "g4s_knn_workspace": (c_sz, [c_i]),
     "g4s_knn_mean_dist": (c_i, [c_i, c_p, c_p, c_p, c_sz, c_p]),
     "g4s_rasterizer_layout": (c_i, [c_i, c_i, c_i, c_i, ctypes.POINTER(G4sLayout)]),
+    "g4s_set_option": (c_i, [ctypes.c_char_p, c_i]),
+    "g4s_get_option": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
     "g4s_pack_rows": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "g4s_profile_enable": (None, [c_i]),
     "g4s_profile_kernels": (c_i, []),
@@ -101,3 +103,36 @@ def load():
 
 def last_error():
     return load().g4s_last_error().decode()
+
+
+OPTION_UNSET = -2147483648  # G4S_OPTION_UNSET
+
+
+def set_option(name, value):
+    """Diagnostic switch of the library (include/g4s_rasterizer.h: g4s_set_option).  The library never reads the
+    environment on a call path; the parity tests flip these instead."""
+    if load().g4s_set_option(name.encode(), int(value)) != 0:
+        raise ValueError(last_error())
+
+
+def get_option(name):
+    v = c_i(0)
+    if load().g4s_get_option(name.encode(), ctypes.byref(v)) != 0:
+        raise ValueError(last_error())
+    return v.value
+
+
+class option:
+    """`with _lib.option("no_fastpath", 1): ...` -- sets a diagnostic switch and restores its previous value."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False

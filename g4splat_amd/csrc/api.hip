@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -60,6 +61,14 @@ hipEvent_t readback_event() {
     }
     return ev[dev];
 }
+
+// Diagnostic switches (include/g4s_rasterizer.h: g4s_set_option).  Plain process-wide integers: read on every call,
+// written only by g4s_set_option -- the call paths never touch the environment.
+struct Option { const char* name; std::atomic<int> value; };
+Option g_options[] = {{"box_only", {0}}, {"no_fastpath", {0}}, {"bwd_fwd_order", {0}},
+                      {"bwd_hot_threshold", {G4S_OPTION_UNSET}}, {"no_side_zero", {0}}, {"no_pairs", {0}}};
+enum OptionId { OPT_BOX_ONLY, OPT_NO_FASTPATH, OPT_BWD_FWD_ORDER, OPT_BWD_HOT_THRESHOLD, OPT_NO_SIDE_ZERO, OPT_NO_PAIRS };
+inline int opt(OptionId id) { return g_options[id].value.load(std::memory_order_relaxed); }
 
 inline bool trace_on() {
     static const bool on = getenv("G4S_TRACE") != nullptr;
@@ -170,6 +179,16 @@ extern "C" void g4s_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.clear();
     g_prof_next = 0;  // the pooled events are reused
+}
+extern "C" int g4s_set_option(const char* name, int value) {
+    for (Option& o : g_options)
+        if (name && !strcmp(name, o.name)) { o.value.store(value, std::memory_order_relaxed); return G4S_OK; }
+    return fail(G4S_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+}
+extern "C" int g4s_get_option(const char* name, int* value) {
+    for (Option& o : g_options)
+        if (name && !strcmp(name, o.name)) { if (value) *value = o.value.load(std::memory_order_relaxed); return G4S_OK; }
+    return fail(G4S_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
 }
 extern "C" const char* g4s_version(void) { return "g4s-hip 0.1.0 gfx950"; }
 
@@ -406,8 +425,9 @@ static int rasterizer_forward_impl(
     ba.ranges = ranges; ba.tile_order = tile_order; ba.entries = entries_ptr; ba.rec = rec_ptr; ba.bg = background;
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
     ba.qhit = qhit_ptr;
-    ba.box_only = getenv("G4S_BOX_ONLY") != nullptr;
-    ba.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
+    ba.box_only = opt(OPT_BOX_ONLY) != 0;
+    ba.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
+    ba.no_pairs = opt(OPT_NO_PAIRS) != 0;
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");
     return R;
@@ -525,14 +545,15 @@ static int rasterizer_backward_impl(
         // backward order: most blended (entry, quadrant) pairs first -- the forward counted them per tile
         uint32_t* tile_order_bwd = (uint32_t*)(img + IL.tile_order_bwd);
         launch_tile_order(tiles, (const uint32_t*)(img + IL.tile_depth), tile_order_bwd, stream, hot_count);
-        bb.tile_order = getenv("G4S_BWD_FWD_ORDER") ? (const uint32_t*)(img + IL.tile_order) : tile_order_bwd;
+        bb.tile_order = opt(OPT_BWD_FWD_ORDER) ? (const uint32_t*)(img + IL.tile_order) : tile_order_bwd;
         bb.entries = (const uint64_t*)(bin + ((passes & 1) ? BL.ent_b : BL.ent_a));
         bb.rec = rec; bb.bg = background;
         bb.final_T = (const float*)(img + IL.final_T);
         bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
-        bb.no_fastpath = getenv("G4S_NO_FASTPATH") != nullptr;
+        bb.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
+        bb.no_pairs = opt(OPT_NO_PAIRS) != 0;
         // One wave per tile is the efficient form when there are enough tiles to fill the GPU (1 024 SIMDs x 3
         // waves); a small frame (<= 768 tiles, e.g. 256 x 256) runs about twice as fast with four waves per tile,
         // and so does any single tile that is much deeper than the rest (measured: tools/deep_tile_bench.py).
@@ -541,12 +562,13 @@ static int rasterizer_backward_impl(
         // faster form, the four-wave kernel does ~1.9x the work per tile.
         const long long avg_list = (long long)R / (tiles > 0 ? tiles : 1);
         const long long outlier = 4 * avg_list > BWD_HOT_THRESHOLD ? 4 * avg_list : BWD_HOT_THRESHOLD;
-        bb.hot_threshold = getenv("G4S_BWD_HOT_THRESHOLD") ? atoi(getenv("G4S_BWD_HOT_THRESHOLD"))
+        const int hot_override = opt(OPT_BWD_HOT_THRESHOLD);
+        bb.hot_threshold = hot_override != G4S_OPTION_UNSET ? hot_override
                            : (tiles <= BWD_FOUR_WAVE_MAX_TILES ? -1 : (int)(outlier < 0x7fffffff ? outlier : 0x7fffffff));
         bb.hot_count = hot_count; bb.hot_list = hot_list;
         // dL_dsh is mostly zero rows (invisible Gaussians).  When the one-wave kernel runs, its workgroups clear the
         // tensor on the side (blend.hip) and K8 writes the visible rows only; otherwise K8 clears the rows it skips.
-        if (bb.hot_threshold >= 0 && M > 0 && !getenv("G4S_NO_SIDE_ZERO")) {
+        if (bb.hot_threshold >= 0 && M > 0 && !opt(OPT_NO_SIDE_ZERO)) {
             float* zb[2] = {dL_dsh, dL_dsh_rest};
             const size_t zn[2] = {(size_t)P * (dL_dsh_rest ? 1 : M) * 3, dL_dsh_rest ? (size_t)P * (M - 1) * 3 : 0};
             bool ok = true;

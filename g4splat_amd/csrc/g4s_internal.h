@@ -184,8 +184,9 @@ struct BlendFwdArgs {
     uint32_t* n_contrib;
     uint8_t* qhit;  // per sorted instance: bit q set if some pixel of quadrant q blended it (pre-zeroed)
     uint32_t* tile_depth;  // per tile (0, number of (entry, quadrant) pairs blended): the backward's work, for its ordering
-    int box_only;   // experiments / tests (G4S_BOX_ONLY): skip quadrants by the bounding box only
-    int no_fastpath;  // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
+    int box_only;   // tests (option "box_only"): skip quadrants by the bounding box only
+    int no_fastpath;  // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
+    int no_pairs;     // tests (option "no_pairs"): visit the list entries one at a time
     float* out_color;
     float* out_others;
 };
@@ -205,7 +206,8 @@ struct BlendBwdArgs {
     const float* dL_depths;
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
     uint8_t* rec_flag; // R bytes (binning chunk, cleared by the forward's emit): bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
-    int no_fastpath;   // experiments / tests (G4S_NO_FASTPATH): ignore REC_NO_LOWPASS
+    int no_fastpath;   // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
+    int no_pairs;      // tests (option "no_pairs"): visit the list entries one at a time
     // deep tiles (more than hot_threshold live list positions) are left to blend_bwd_hot_kernel: the one-wave
     // kernel appends them to hot_list (hot_count pre-cleared), the four-wave kernel runs behind it
     int hot_threshold;  // < 0: all tiles go to the four-wave kernel (frames with too few tiles to fill the GPU one wave each)
@@ -218,7 +220,7 @@ struct BlendBwdArgs {
     uint32_t zero_quads[2];   // float4 count
     uint32_t zero_tail[2];    // 0..3 floats behind the quads
 };
-constexpr int BWD_HOT_THRESHOLD = 2048;  // live list positions; override for tests: G4S_BWD_HOT_THRESHOLD
+constexpr int BWD_HOT_THRESHOLD = 2048;  // live list positions; override for tests: option "bwd_hot_threshold"
 constexpr int BWD_FOUR_WAVE_MAX_TILES = 768;  // frames with at most this many tiles use the four-wave kernel throughout
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 

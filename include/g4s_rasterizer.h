@@ -222,6 +222,20 @@ typedef struct g4s_layout {
 
 int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
 
+/* Diagnostic switches of the parity tests -- process-wide integers held by the library, default 0 / unset.  They are
+ * set through this call only: the library never reads the environment on a call path.  None of them changes a result
+ * beyond rounding (the tests assert exactly that):
+ *   "box_only"           forward skips quadrants by the bounding box only, not by the exact cutoff region
+ *   "no_fastpath"        every splat takes the general per-pixel evaluation (REC_NO_LOWPASS ignored)
+ *   "bwd_fwd_order"      the blend backward walks the tiles in the forward's order
+ *   "bwd_hot_threshold"  list depth above which a tile goes to the four-wave backward (G4S_OPTION_UNSET = automatic)
+ *   "no_side_zero"       the blend backward does not clear dL_dsh on the side (K8 clears the rows it skips)
+ *   "no_pairs"           the blend kernels visit list entries one at a time (no packed-FP32 pair visits)
+ * Returns G4S_OK or G4S_ERR_INVALID_ARGUMENT for an unknown name. */
+#define G4S_OPTION_UNSET (-2147483647 - 1)
+int g4s_set_option(const char* name, int value);
+int g4s_get_option(const char* name, int* value);
+
 /*
  * Row packing for the multi-GPU gradient exchange (new functionality; no reference
  * counterpart): gathers the rows `row_index[0..n)` of up to 8 row-major float segments

@@ -60,6 +60,32 @@ def test_version_and_error_strings(hip_lib):
     assert b"bad layout" in hip_lib.g4s_last_error()
 
 
+def test_diagnostic_switches_are_library_state_not_environment(hip_lib):
+    """The test switches are integers held by the library (g4s_set_option): round trip, unknown names refused, and no
+    translation unit calls getenv outside the one-time G4S_TRACE probe (nothing on a call path depends on the
+    caller's environment)."""
+    from g4splat_amd import _lib
+    for name in ("box_only", "no_fastpath", "bwd_fwd_order", "no_side_zero", "no_pairs"):
+        assert _lib.get_option(name) == 0
+        with _lib.option(name, 1):
+            assert _lib.get_option(name) == 1
+        assert _lib.get_option(name) == 0
+    assert _lib.get_option("bwd_hot_threshold") == _lib.OPTION_UNSET
+    with _lib.option("bwd_hot_threshold", 40):
+        assert _lib.get_option("bwd_hot_threshold") == 40
+    assert _lib.get_option("bwd_hot_threshold") == _lib.OPTION_UNSET
+    with pytest.raises(ValueError, match="unknown option"):
+        _lib.set_option("no_such_switch", 1)
+    csrc = os.path.join(ROOT, "g4splat_amd", "csrc")
+    uses = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if "getenv" in line and not line.lstrip().startswith("//"):
+                    uses.append((f, i, line.strip()))
+    assert len(uses) == 1 and "G4S_TRACE" in uses[0][2] and "static" in uses[0][2], uses
+
+
 def test_argument_validation_is_host_side(hip_lib):
     """Every entry point rejects bad arguments before it touches the device: negative status + a message, no launch."""
     import ctypes

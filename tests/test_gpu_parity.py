@@ -333,13 +333,17 @@ def test_config5_three_million_surfels(hip_lib, oracle_mod, capsys):
 
 @pytest.mark.parametrize("backward", ["policy", "one-wave"])
 @pytest.mark.parametrize("block", range(20))
-def test_fuzz_small_scenes(hip_lib, oracle_mod, block, backward, monkeypatch):
+def test_fuzz_small_scenes(hip_lib, oracle_mod, block, backward):
     """Two hundred seeded random configurations (image sizes that are not multiples of the tile, 1-pixel-high images,
     huge and tiny splats, translucent and opaque, every SH degree, scale modifiers, backgrounds, fields of view)
     against the oracle: outputs, radii, instance counts, culled tile lists, gradients.  Frames this small take the
     four-wave backward under the default policy; "one-wave" forces the one-wave-per-tile kernel on the same cases."""
-    if backward == "one-wave":
-        monkeypatch.setenv("G4S_BWD_HOT_THRESHOLD", str(1 << 30))
+    from g4splat_amd import _lib
+    with _lib.option("bwd_hot_threshold", (1 << 30) if backward == "one-wave" else _lib.OPTION_UNSET):
+        _fuzz_block(oracle_mod, block)
+
+
+def _fuzz_block(oracle_mod, block):
     for case in range(10):
         seed = 1000 + 10 * block + case
         rng = np.random.default_rng(seed)
@@ -360,30 +364,26 @@ def test_fuzz_small_scenes(hip_lib, oracle_mod, block, backward, monkeypatch):
             check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
 
 
-@pytest.mark.parametrize("switch", ["G4S_BOX_ONLY", "G4S_NO_FASTPATH", "G4S_BWD_FWD_ORDER"])
+@pytest.mark.parametrize("switch", ["box_only", "no_fastpath", "bwd_fwd_order"])
 def test_shortcuts_never_change_a_result(hip_lib, switch):
-    """Two shortcuts of the blend kernels are pure work-savers and can be switched off from the environment:
-      G4S_BOX_ONLY     the forward skips quadrants by the bounding box only, not by the exact cutoff ellipse;
-      G4S_NO_FASTPATH  every splat takes the general per-pixel evaluation, also those whose record says that the
-                       low-pass exponent can never matter (REC_NO_LOWPASS);
-      G4S_BWD_FWD_ORDER  the backward walks the tiles in the forward's order (by list length) instead of its own
-                       (by blended pairs) -- scheduling only.
+    """Shortcuts of the blend kernels that are pure work-savers can be switched off (g4s_set_option; the library reads
+    no environment variable on a call path):
+      box_only       the forward skips quadrants by the bounding box only, not by the exact cutoff ellipse;
+      no_fastpath    every splat takes the general per-pixel evaluation, also those whose record says that the
+                     low-pass exponent can never matter (REC_NO_LOWPASS);
+      bwd_fwd_order  the backward walks the tiles in the forward's order (by list length) instead of its own
+                     (by blended pairs) -- scheduling only.
     With either one off every output, the blend state and all gradients must be bit-identical -- on random small
     scenes (thin, huge, tiny, sub-pixel, translucent splats, wide fields of view) and at the metric's size."""
-    import os
     import torch
-    from g4splat_amd import synthetic
+    from g4splat_amd import _lib, synthetic
 
     def both(inp):
         outs = []
         g = cotangents(inp["H"], inp["W"], seed=7)
-        for box_only in (False, True):
-            if box_only:
-                os.environ[switch] = "1"
-            try:
+        for off in (0, 1):
+            with _lib.option(switch, off):
                 h = run_hip(inp, g)  # the gradients depend on the contribution masks the forward records
-            finally:
-                os.environ.pop(switch, None)
             st = hip_state(h, inp)
             outs.append([h["color"], h["others"], st["final_T"].copy(), st["n_contrib"].copy()] +
                         [h["grads"][k] for k in sorted(h["grads"])])
@@ -428,7 +428,7 @@ def test_hot_tiles(hip_lib, oracle_mod):
 
 
 def test_deep_tile_backward_matches_the_one_wave_backward(hip_lib, oracle_mod):
-    """Tiles deeper than G4S_BWD_HOT_THRESHOLD live list positions go through the four-wave backward
+    """Tiles deeper than the option "bwd_hot_threshold" live list positions go through the four-wave backward
     (blend_bwd_hot_kernel).  With the threshold at 0 (every tile) and at 40 (a mix of both kernels in one launch) the
     gradients must equal the one-wave kernel's to rounding -- the partial sums are associated differently --, be
     bit-reproducible, and pass the oracle bar; random small scenes, and the metric-size scene against the default."""
@@ -437,13 +437,11 @@ def test_deep_tile_backward_matches_the_one_wave_backward(hip_lib, oracle_mod):
     import torch
     from g4splat_amd import synthetic
 
+    from g4splat_amd import _lib
+
     def grads_with(inp, g, threshold):
-        if threshold is not None:
-            os.environ["G4S_BWD_HOT_THRESHOLD"] = str(threshold)
-        try:
+        with _lib.option("bwd_hot_threshold", _lib.OPTION_UNSET if threshold is None else threshold):
             return run_hip(inp, g)
-        finally:
-            os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
 
     for seed in range(40):
         rng = np.random.default_rng(900 + seed)
@@ -501,11 +499,9 @@ def test_outlier_tiles_in_a_full_frame(hip_lib, oracle_mod):
     last = st["n_contrib"][0].reshape(480, 640)
     deep = last.reshape(30, 16, 40, 16).max(axis=(1, 3))
     assert (deep > 2048).sum() >= 2 and (deep > 2048).sum() < 60, (deep > 2048).sum()  # a few outlier tiles
-    os.environ["G4S_BWD_HOT_THRESHOLD"] = str(1 << 30)
-    try:
+    from g4splat_amd import _lib
+    with _lib.option("bwd_hot_threshold", 1 << 30):
         one_wave = run_hip(inp, g)
-    finally:
-        os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
     differs = False
     for k in h["grads"]:
         a, b = one_wave["grads"][k], h["grads"][k]
@@ -626,12 +622,13 @@ def test_presized_forward_never_blocks_the_host_and_matches(hip_lib):
 
 
 @pytest.mark.parametrize("P", [20001, 20003])
-def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P, monkeypatch):
+def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P):
     """dL_dsh is mostly zero rows (invisible Gaussians).  In frames that run the one-wave blend backward those rows are
     cleared by that kernel's workgroups on the side (api.hip / blend.hip: BlendBwdArgs::zero_*), elsewhere by K8 itself
-    (G4S_NO_SIDE_ZERO forces that path).  Both must write every element of caller-provided, NaN-filled outputs and
+    (option "no_side_zero" forces that path).  Both must write every element of caller-provided, NaN-filled outputs and
     agree bit for bit -- packed SH and split SH, row counts that leave 0..3 floats behind the last 16-byte store."""
     import torch
+    from g4splat_amd import _lib
     from g4splat_amd.diff_surfel_rasterization import _C
     inp = scene_inputs(P=P, W=640, H=480, seed=23, D=3, bg=(0.1, 0.2, 0.3))  # 1 200 tiles: the one-wave kernel runs
     gr = cotangents(480, 640, seed=6)
@@ -641,10 +638,7 @@ def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P, monkeypa
     t = lambda x: torch.as_tensor(x, device="cuda:0")
     results = {}
     for side in (True, False):
-        if side:
-            monkeypatch.delenv("G4S_NO_SIDE_ZERO", raising=False)
-        else:
-            monkeypatch.setenv("G4S_NO_SIDE_ZERO", "1")
+        _lib.set_option("no_side_zero", 0 if side else 1)
         for split in (False, True):
             sh = (a["sh"][:, :1].contiguous(), a["sh"][:, 1:].contiguous()) if split else a["sh"]
             fw = _C.rasterize_gaussians(a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"], a["rotations"], 1.0,
@@ -665,7 +659,7 @@ def test_sh_gradient_rows_cleared_beside_the_blend_backward(hip_lib, P, monkeypa
                 assert dsh.data_ptr() == out["dL_dsh"].data_ptr()
             results[(side, split)] = dsh.cpu().numpy()
     # an output view that is only 4-byte aligned: no 16-byte stores anywhere, K8 clears the rows itself
-    monkeypatch.delenv("G4S_NO_SIDE_ZERO", raising=False)
+    _lib.set_option("no_side_zero", 0)
     fw = _C.rasterize_gaussians(a["bg"], a["means3D"], a["colors"], a["opacity"], a["scales"], a["rotations"], 1.0,
                                 a["transMat"], a["view"], a["proj"], inp["tanfovx"], inp["tanfovy"], inp["H"], inp["W"],
                                 a["sh"], inp["D"], a["campos"], False, False)

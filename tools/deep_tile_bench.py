@@ -1,5 +1,5 @@
 """Backward time on a frame whose work sits in a few very deep tiles (the one-wave-per-tile kernel's worst case),
-with and without the four-wave deep-tile kernel (G4S_BWD_HOT_THRESHOLD), and on the metric workload.
+with and without the four-wave deep-tile kernel (option "bwd_hot_threshold"), and on the metric workload.
 
     python tools/deep_tile_bench.py"""
 import os
@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from common import cotangents, scene_inputs  # noqa: E402
 from g4splat_amd.diff_surfel_rasterization import _C  # noqa: E402
+from g4splat_amd import _lib  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -26,10 +27,7 @@ def run(inp, label):
                                 a["sh"], inp["D"], a["campos"], False, False)
     R, _c, _o, radii, geom, binning, img = fw
     for thr in ("default", "1000000000", "0"):
-        if thr != "default":
-            os.environ["G4S_BWD_HOT_THRESHOLD"] = thr
-        else:
-            os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
+        _lib.set_option("bwd_hot_threshold", int(thr) if thr != "default" else _lib.OPTION_UNSET)
         ts = []
         for _ in range(6):
             torch.cuda.synchronize()
@@ -40,7 +38,7 @@ def run(inp, label):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         print(f"{label}: R={R} threshold={thr:>10s}: backward {1e3 * min(ts):8.3f} ms", flush=True)
-    os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
+    _lib.set_option("bwd_hot_threshold", _lib.OPTION_UNSET)
 
 
 run(scene_inputs(P=60000, W=48, H=32, seed=77, D=1, opacity_max=0.03, scale_mul=4.0, fov_deg=110.0), "6 deep tiles (10^4 each)")

@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from common import cotangents, hip_state, run_hip, run_oracle, scene_inputs  # noqa: E402
 import oracle.oracle as oracle_mod  # noqa: E402
+from g4splat_amd import _lib  # noqa: E402
 
 for seed in [int(x) for x in sys.argv[1:]]:
     rng = np.random.default_rng(seed)
@@ -32,10 +33,9 @@ for seed in [int(x) for x in sys.argv[1:]]:
     g = cotangents(H, W, seed=seed)
     o = run_oracle(oracle_mod, inp, g)
     print(f"seed {seed}: P={P} {W}x{H} D={D} kind={kind} R={o['R']} scale_modifier={inp['scale_modifier']}")
-    for env in ({}, {"G4S_BOX_ONLY": "1"}, {"G4S_NO_FASTPATH": "1"}):
-        for k in ("G4S_BOX_ONLY", "G4S_NO_FASTPATH"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+    for env in ({}, {"box_only": 1}, {"no_fastpath": 1}):
+        for k in ("box_only", "no_fastpath"):
+            _lib.set_option(k, env.get(k, 0))
         h = run_hip(inp, g)
         d = np.abs(h["color"] - o["color"]).max(axis=0)
         do = np.abs(h["others"] - o["others"]).max(axis=0)
@@ -49,5 +49,5 @@ for seed in [int(x) for x in sys.argv[1:]]:
               "max |depth|", float(np.abs(o["others"][0]).max()), "max |median|", float(np.abs(o["others"][5]).max()))
         print(f"   {env or 'default'}: {nbad} pixels beyond 1e-4, worst {d.max():.3e} at ({x},{y}) others worst {do.max():.3e}; "
               f"alpha hip {h['others'][1][y, x]:.6f} oracle {o['others'][1][y, x]:.6f}; last contributor hip(list pos) {last_h} oracle {last_o}")
-    for k in ("G4S_BOX_ONLY", "G4S_NO_FASTPATH"):
-        os.environ.pop(k, None)
+    for k in ("box_only", "no_fastpath"):
+        _lib.set_option(k, 0)

@@ -17,6 +17,7 @@ from common import cotangents, hip_state, run_hip, run_oracle, scene_inputs  # n
 from common import GRAD_RTOL, OUT_ATOL, assert_parity, rel_err  # noqa: E402
 from test_gpu_parity import check_lists_against_oracle  # noqa: E402
 import oracle.oracle as oracle_mod  # noqa: E402
+from g4splat_amd import _lib  # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
@@ -63,10 +64,7 @@ for seed in range(first, first + count):
         g = (gc, go)
     o = run_oracle(oracle_mod, inp, g)
     for mode in ("policy", "one-wave"):
-        if mode == "one-wave":
-            os.environ["G4S_BWD_HOT_THRESHOLD"] = str(1 << 30)
-        else:
-            os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
+        _lib.set_option("bwd_hot_threshold", (1 << 30) if mode == "one-wave" else _lib.OPTION_UNSET)
         h = run_hip(inp, g)
         tag = f"seed {seed} {mode}: P={P} {W}x{H} D={D} kind={kind}"
         try:
@@ -106,11 +104,10 @@ for seed in range(first, first + count):
                     continue
                 assert rel_err(h["grads"][name], o["grads"][name]) <= GRAD_RTOL, "grad " + name
         except AssertionError as ex:
-            # a mismatch that survives G4S_BOX_ONLY is a threshold flip of the per-pixel arithmetic (one contributor at
+            # a mismatch that survives box_only is a threshold flip of the per-pixel arithmetic (one contributor at
             # alpha ~ 1/255 or T ~ 1e-4 decided the other way: ~1e-7 of the pixels); one that disappears is a culling bug
-            os.environ["G4S_BOX_ONLY"] = "1"
-            hb = run_hip(inp, g)
-            os.environ.pop("G4S_BOX_ONLY", None)
+            with _lib.option("box_only", 1):
+                hb = run_hip(inp, g)
             cured = (np.abs(hb["color"] - o["color"]).max() <= OUT_ATOL and np.abs(hb["others"] - o["others"]).max() <= OUT_ATOL)
             npx = int((np.abs(h["color"] - o["color"]).max(axis=0) > OUT_ATOL).sum())
             kind_s = "CULLING BUG" if cured and str(ex) in ("color", "others") else "threshold flip" if str(ex) in ("color", "others") else "other"
@@ -118,7 +115,7 @@ for seed in range(first, first + count):
             print("MISMATCH", tag, ex, kind_s, f"{npx} pixels", flush=True)
     if (seed - first) % 100 == 99:
         print(f"{seed - first + 1} scenes, {len(bad)} mismatches", flush=True)
-os.environ.pop("G4S_BWD_HOT_THRESHOLD", None)
+_lib.set_option("bwd_hot_threshold", _lib.OPTION_UNSET)
 print(f"done: {count} scenes x 2 backward kernels, {len(bad)} mismatches")
 for b in bad:
     print(" ", b)

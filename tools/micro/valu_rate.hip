@@ -4,12 +4,22 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int KIND>
-__global__ void __launch_bounds__(256) k(float* out, int iters) {
+__global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long long* cyc) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float lds[1024];
     float a[8];
     double b[4];
+    f2 c[4];
+    f4 q[4];
+    for (int i = 0; i < 4; i++) { c[i].x = 1.0f + threadIdx.x * 1e-3f + i; c[i].y = 2.0f + i; q[i] = f4{0, 0, 0, 0}; }
+    for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = (float)i;
+    __syncthreads();
+    const uint32_t lds_addr = (uint32_t)(size_t)lds + (iters & 1) * 64;  // wave-uniform address
     for (int i = 0; i < 8; i++) a[i] = 1.0f + threadIdx.x * 1e-3f + i;
     for (int i = 0; i < 4; i++) b[i] = 1.0 + threadIdx.x * 1e-3 + i;
     asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[0]), "v"(a[1]) : "vcc");  // a defined vcc
+    const unsigned long long t0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -29,32 +39,56 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
             if (KIND == 9 && (i & 1) == 0) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(a[i + 1]));
             if (KIND == 10) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(a[(i + 1) & 7]) : "vcc");
             if (KIND == 11) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            // packed FP32 (two floats per lane per instruction; an instruction counts once): four independent register pairs
+            if (KIND == 16 && i < 4) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(c[i]));
+            if (KIND == 17 && i < 4) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(c[i]));
+            if (KIND == 18 && i < 4) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(c[i]));
+            // low half of src0 broadcast to both results, src2 negated: the shape of k = px * Tw - Tu for two list entries
+            if (KIND == 19 && i < 4) asm volatile("v_pk_fma_f32 %0, %1, %0, %2 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(c[i]) : "v"(c[(i + 1) & 3]), "v"(c[(i + 2) & 3]));
+            if (KIND == 20 && i < 4) asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[1,0]" : "+v"(c[i]) : "v"(c[(i + 1) & 3]));
+            // the blend loops' mix: six packed fma per transcendental
+            if (KIND == 21) { if (i < 6) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(c[i & 3])); else if (i == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(a[0])); else asm volatile("v_rcp_f32 %0, %0" : "+v"(a[1])); }
+            if (KIND == 22) { if (i < 6) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i])); else if (i == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(a[6])); else asm volatile("v_rcp_f32 %0, %0" : "+v"(a[7])); }
+            // wave-uniform (broadcast) LDS reads, alone and beside VALU work: what feeds the blend loops their list entries
+            if (KIND == 23 && i < 4) asm volatile("ds_read_b128 %0, %1 offset:0\n\ts_waitcnt lgkmcnt(0)" : "=v"(q[i]) : "v"(lds_addr + 16 * i) : "memory");
+            if (KIND == 24) { if (i == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(q[0]) : "v"(lds_addr) : "memory"); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i])); if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            if (KIND == 25) { if (i < 2) asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(lds_addr + 16 * i) : "memory"); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i])); if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            if (KIND == 26) { if (i < 4) asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(lds_addr + 16 * i) : "memory"); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i])); if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            if (KIND == 27) { if (i < 4) asm volatile("ds_read_b64 %0, %1" : "=v"(c[i]) : "v"(lds_addr + 8 * i) : "memory"); asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i])); if (i == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         }
     }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
     float s = 0;
     for (int i = 0; i < 8; i++) s += a[i];
-    for (int i = 0; i < 4; i++) s += (float)b[i];
+    for (int i = 0; i < 4; i++) s += (float)b[i] + c[i].x + c[i].y + q[i].x + q[i].w;
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+static unsigned long long* d_cyc;
 template <int KIND>
-void run(const char* name, float* d) {
+void run(const char* name, float* d, int per_iter = 8) {
     const int iters = 4096, blocks = 256 * 4;  // 4 blocks of 4 waves per CU: 4 waves per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 16);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 16, d_cyc);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, iters, d_cyc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double insts_per_simd = (double)iters * 8 * 4;       // 4 waves per SIMD
+    const double insts_per_simd = (double)iters * per_iter * 4;       // 4 waves per SIMD
     const double cycles = ms * 1e-3 * 2.4e9;
-    printf("%-28s %.3f ms  %.2f cycles per wave instruction (at 2.4 GHz)\n", name, ms, cycles / insts_per_simd);
+    unsigned long long ticks = 0;
+    hipMemcpy(&ticks, d_cyc, 8, hipMemcpyDeviceToHost);
+    // the kernel's own shader-clock count (one wave of block 0) separates the issue cost from the clock the part ran at
+    printf("%-44s %.3f ms  %.2f cyc/instr at a nominal 2.4 GHz | %.2f shader-clock ticks/instr, ticks/us %.0f\n", name, ms,
+           cycles / insts_per_simd, (double)ticks / insts_per_simd, (double)ticks / (ms * 1e3));
 }
 int main() {
     float* d;
     hipMalloc(&d, 256 * 4 * 256 * 4);
+    hipMalloc(&d_cyc, 8);
     run<0>("v_fma_f32", d);
     run<1>("v_rcp_f32", d);
     run<2>("v_exp_f32", d);
@@ -71,5 +105,17 @@ int main() {
     run<9>("v_permlane32_swap (x4, +s_nop)", d);
     run<10>("v_cmp_lt_f32 -> vcc", d);
     run<11>("v_add_f32_dpp quad_perm", d);
+    run<16>("v_pk_fma_f32", d, 4);
+    run<17>("v_pk_mul_f32", d, 4);
+    run<18>("v_pk_add_f32", d, 4);
+    run<19>("v_pk_fma_f32 op_sel+neg", d, 4);
+    run<20>("v_pk_mov_b32", d, 4);
+    run<21>("6 v_pk_fma + exp + rcp (per instr)", d, 8);
+    run<22>("6 v_fma + exp + rcp (per instr)", d, 8);
+    run<23>("ds_read_b128 uniform, waited", d, 4);
+    run<24>("8 v_fma + 1 ds_read_b128 (per group of 8)", d, 1);
+    run<25>("8 v_fma + 2 ds_read_b128 (per group of 8)", d, 1);
+    run<26>("8 v_fma + 4 ds_read_b128 (per group of 8)", d, 1);
+    run<27>("8 v_fma + 4 ds_read_b64 (per group of 8)", d, 1);
     return 0;
 }
