@@ -552,6 +552,7 @@ static int rasterizer_backward_impl(
         bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
+        bb.n_slots = (uint32_t)R;
         bb.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
         bb.no_pairs = opt(OPT_NO_PAIRS) != 0;
         // One wave per tile is the efficient form when there are enough tiles to fill the GPU (1 024 SIMDs x 3
@@ -596,7 +597,7 @@ static int rasterizer_backward_impl(
     pb.transMat_precomp = transMat_precomp; pb.colors_precomp = colors_precomp;
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
-    pb.rec_flag = rec_flag;
+    pb.rec_flag = rec_flag; pb.n_slots = (uint32_t)R;
     pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest; pb.sh_prezeroed = sh_prezeroed;
     pb.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
@@ -857,9 +858,12 @@ extern "C" int g4s_pack_rows(int nseg, float* const* segments, const int* widths
     const int debug = 0;
     t_err[0] = 0;
     if (nseg < 1 || nseg > 8 || n < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "1..8 segments, n >= 0");
-    if (unpack < 0 || unpack > 7 || ((unpack & 4) && !(unpack & 1)))
-        return fail(G4S_ERR_INVALID_ARGUMENT, "mode: bit 0 unpack, bit 1 row-major buffer, bit 2 add (unpack only)");
-    if (!segments || !widths || (n > 0 && (!row_index || !packed))) return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
+    if (unpack < 0 || unpack > 15 || ((unpack & 4) && !(unpack & 1)) || ((unpack & 8) && !(unpack & 2)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "mode: bit 0 unpack, bit 1 row-major buffer, bit 2 add (unpack only), "
+                                              "bit 3 index column (row-major only)");
+    const bool idx_from_buffer = (unpack & 9) == 9;
+    if (!segments || !widths || (n > 0 && ((!row_index && !idx_from_buffer) || !packed)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
     for (int i = 0; i < nseg; i++)
         if (!segments[i] || widths[i] <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: NULL pointer or width <= 0", i);
     g4s_pack_rows_launch_internal(nseg, segments, widths, row_index, n, packed, unpack, stream);

@@ -206,6 +206,11 @@ struct BlendBwdArgs {
     const float* dL_depths;
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so
     uint8_t* rec_flag; // R bytes (binning chunk, cleared by the forward's emit): bit 0 = terms 0..15 written, bit 1 = low-pass terms 16..17 written
+    // Record slots that exist (= the R both buffers were sized for).  A presized forward that overflowed its capacity
+    // keeps the first `capacity` instances in depth order, but a kept instance's slot (inst_off + k, an index-order
+    // scan over ALL binned instances) can lie beyond it: such a record is dropped, never written (the frame is
+    // flagged invalid in the status word; memory stays safe).
+    uint32_t n_slots;
     int no_fastpath;   // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
     int no_pairs;      // tests (option "no_pairs"): visit the list entries one at a time
     // deep tiles (more than hot_threshold live list positions) are left to blend_bwd_hot_kernel: the one-wave
@@ -233,6 +238,7 @@ struct PreprocessBwdArgs {
     const uint8_t* clamped;
     const float* grad_inst;
     const uint8_t* rec_flag;
+    uint32_t n_slots;  // record slots that exist (see BlendBwdArgs::n_slots): slot runs are clamped to them
     bool sh_vec16;  // shs and dL_dsh are [P,16,3] on 16-byte aligned bases
     const float* shs_rest;  // split layout: shs / dL_dsh are the [P,1,3] parts, shs_rest / dL_dsh_rest the [P,M-1,3] ones
     float* dL_dsh_rest;

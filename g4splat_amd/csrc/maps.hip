@@ -296,6 +296,8 @@ extern "C" void g4s_maps_launch_internal(int fwd, int W, int H, float depth_rati
 //             packed[j * sum_w + seg_off(s) + c] -- what an all_to_all with per-destination row ranges needs)
 // mode bit 2: unpack ADDS to the rows instead of overwriting them (the owner's accumulation of one source's rows; a
 //             source holds a row at most once, so there are no duplicate indices inside one launch)
+// mode bit 3: (row-major only) buffer rows are sum w + 1 floats: the last one is the row's index as int32 bits --
+//             pack writes it, unpack reads it instead of idx[] (idx may be NULL then)
 // A row's floats over all segments (58 + 2 for the gradient bucket) are spread over the lanes of a wave --
 // lane -> (segment, column) is fixed for the whole kernel, so there is no per-element division -- and each wave
 // walks rows j, j + #waves, ...: both sides move contiguous w_s-float runs.  Rows wider than 64 floats take
@@ -310,10 +312,13 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(RowSegs segs, const long
                                                         float* __restrict__ packed, int mode) {
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), nwaves = (int)(gridDim.x * 4);
-    const bool unpack = (mode & 1) != 0, row_major = (mode & 2) != 0, add = (mode & 4) != 0;
+    const bool unpack = (mode & 1) != 0, row_major = (mode & 2) != 0, add = (mode & 4) != 0, carry = (mode & 8) != 0;
     int row_floats = 0;
     for (int s = 0; s < segs.nseg; s++) row_floats += segs.width[s];
-    for (int f0 = 0; f0 < row_floats; f0 += 64) {
+    // carry (row-major only): every buffer row ends with its row index as an int32 column -- written by pack, and
+    // read by unpack INSTEAD of idx[] (the rows and their indices then travel in one all_to_all)
+    const int buf_floats = row_floats + (carry ? 1 : 0);
+    for (int f0 = 0; f0 < buf_floats; f0 += 64) {
         // this lane's (segment, column) for float f0 + lane of a row
         const int f = f0 + lane;
         int seg = -1, col = 0, w = 1;
@@ -327,12 +332,19 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(RowSegs segs, const long
                 off += (size_t)segs.width[s];
             }
         }
-        if (seg < 0) continue;
+        const bool index_lane = carry && f == row_floats;
+        if (seg < 0 && !index_lane) continue;
+        if (index_lane) {
+            if (!unpack)
+                for (int j = wave; j < n; j += nwaves) packed[(size_t)j * buf_floats + row_floats] = __int_as_float((int)idx[j]);
+            continue;
+        }
         float* sp = segs.ptr[seg];
         float* pp = row_major ? packed + f : packed + seg_off * (size_t)n + col;
-        const size_t pstride = row_major ? (size_t)row_floats : (size_t)w;
+        const size_t pstride = row_major ? (size_t)buf_floats : (size_t)w;
         for (int j = wave; j < n; j += nwaves) {
-            float* src = sp + (size_t)idx[j] * w + col;
+            const long long row = (carry && unpack) ? (long long)__float_as_int(packed[(size_t)j * buf_floats + row_floats]) : idx[j];
+            float* src = sp + (size_t)row * w + col;
             float* dst = pp + (size_t)j * pstride;
             if (!unpack) *dst = *src;
             else if (add) *src += *dst;

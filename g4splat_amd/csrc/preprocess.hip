@@ -638,6 +638,9 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
         const float4 q0 = rq[0];
         my_off = __float_as_uint(q0.z);
         my_cnt = __float_as_uint(q0.w) & ~REC_NO_LOWPASS;
+        // (only a frame that overflowed its presized capacity has slots beyond the buffers: never read them)
+        if (my_off >= a.n_slots) my_cnt = 0;
+        else if (my_cnt > a.n_slots - my_off) my_cnt = a.n_slots - my_off;
     }
     s_off[t] = my_off;
     s_cnt[t] = my_cnt;

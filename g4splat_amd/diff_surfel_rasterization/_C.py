@@ -222,7 +222,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  out=None):
     """`out` (extension over the reference): optional dict name -> preallocated float32 tensor for any of the
     returned gradients, e.g. views of a persistent all-reduce bucket (parallel.py); the library writes every
-    element of them, so no packing copy is needed before the collective."""
+    element of them, so no packing copy is needed before the collective.  `out["workspace"]`: a uint8 tensor of at
+    least g4s_rasterizer_backward_workspace(P, R) bytes to use instead of a fresh allocation (a training loop keeps
+    one; nothing in it needs clearing).
+
+    The backward reads AND updates the forward's state chunks (the validity bytes of its gradient records live in the
+    binning chunk): run at most one backward at a time per forward state, and with a PresizedState -- whose chunks
+    are shared from frame to frame -- run the backward of a frame before the next forward into the same state."""
     split = isinstance(sh, (tuple, list))
     sh_dc, sh_rest = sh if split else (sh, None)
     for name, t in (("background", background), ("means3D", means3D), ("radii", radii), ("colors", colors),
@@ -272,11 +278,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             dL_dsh = make((P, M, 3), "dL_dsh", **fopt)
         dL_dscales = make((P, 2), "dL_dscales", 8, **fopt)
         dL_drotations = make((P, 4), "dL_drotations", 16, **fopt)
+        workspace = given.pop("workspace", None)
         if given:
             raise RuntimeError(f"unknown out= entries: {sorted(given)}")
         if P != 0:
             ws_bytes = lib.g4s_rasterizer_backward_workspace(P, int(R))
-            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            if workspace is None:
+                workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            elif (workspace.dtype != torch.uint8 or workspace.device != dev or not workspace.is_contiguous()
+                  or workspace.numel() < ws_bytes):
+                raise RuntimeError(f"out['workspace'] must be a contiguous uint8 tensor of >= {ws_bytes} bytes on {dev}")
+            ws_bytes = int(workspace.numel())
             bg, m3, col = _f32c(background), _f32c(means3D), _f32c(colors)
             sc, rot, tm = _f32c(scales, 8), _f32c(rotations, 16), _f32c(transMat_precomp)
             vm, pm, cp = _f32c(viewmatrix), _f32c(projmatrix), _f32c(campos)

@@ -119,28 +119,32 @@ class RowSparseAllReduce:
 class OwnerReduce:
     """Gradient exchange by OWNER-REDUCE over visible rows.
 
-    The Gaussians are split into `world` contiguous index shards; rank d owns shard d.  One step:
+    The Gaussians are split into `world` contiguous index shards; rank d owns shard d.  One step = THREE collectives,
+    all on persistent buffers (nothing is allocated per step; buffers only ever grow):
 
-      begin(visible)   right after the forward (the radii are known): the indices of this rank's visible rows, their
-                       per-owner counts, an all_gather of the counts (world ints per rank) and an asynchronous copy of
-                       the count matrix to the host -- all of it overlaps the backward, so the sizes are on the host
-                       long before they are needed and nothing stalls on them (no `nonzero()` anywhere: the index list
-                       has a fixed, padded size);
-      finish()         after the backward: pack this rank's visible rows row-major (ONE g4s_pack_rows launch on a HIP
-                       device), ONE all_to_all (uneven splits) of rows + ONE of their indices to the owners; the owner
-                       adds what it received from the other ranks INTO ITS OWN SLICE of the gradient tensors, source by
-                       source in ascending rank order (fixed order => bit-reproducible; one accumulating g4s_pack_rows
-                       launch per source); then the reduced shards are all-gathered IN PLACE, one collective per
-                       tensor straight into the gradient tensors (rank d's slice of a [P, w] tensor is contiguous) --
-                       no staging buffer, no copy back.  (P not divisible by the world size: the shards are ragged and
-                       the gather goes through a padded staging buffer instead.)
+      begin(visible, radii)  right after the forward (the radii are known): the indices of this rank's visible rows
+                       (fixed-size list, no host wait), their per-owner counts (two binary searches per owner), and
+                       ONE all-reduce(MAX) over an int32 buffer [P + world^2] that carries the radii (-> max_radii2D,
+                       train_with_refine_depth.py:583) AND the count matrix (rank r fills row r, everything else is
+                       zero, so MAX is a gather); the matrix tail goes to pinned host memory asynchronously.  All of
+                       it overlaps the backward: the sizes are on the host long before they are needed.
+      finish()         after the backward: ONE g4s_pack_rows launch packs this rank's visible rows row-major with their
+                       index as a trailing int32 column, ONE all_to_all (uneven splits) sends them to the owners; the
+                       owner adds what it received INTO ITS OWN SLICE of the gradient tensors, source by source in
+                       ascending rank order (fixed order => bit-reproducible; one accumulating launch per source, the
+                       indices read from the buffer); then (gather=True) the reduced shards are all-gathered IN
+                       PLACE, one collective per tensor issued as one RCCL group, straight into the gradient tensors --
+                       rank d's rows of a contiguous [P, w] tensor are contiguous.  (P not divisible by the world
+                       size: ragged shards go through a padded staging buffer.)  finish(gather=False) stops after
+                       the owner's accumulation: ShardedAdam (below) then steps the owner's shard and gathers
+                       PARAMETERS instead of gradients.
 
     Bytes through a rank's links per step, P Gaussians, w floats per row, visible fraction v, N ranks:
-        all_to_all   v P (N-1)/N (4 w + 8)      sent and received     (dense reduce-scatter: P (N-1)/N 4 w)
+        all_to_all   v P (N-1)/N 4 (w + 1)      sent and received     (dense reduce-scatter: P (N-1)/N 4 w)
         all_gather   P (N-1)/N 4 w              received, P/N 4 w sent to each peer
-    At P = 1.5 M, w = 60, v = 0.28, N = 8: 91 MB + 315 MB instead of 2 x 315 MB for the dense all-reduce, and both
-    collectives are all-pairs patterns that use the seven xGMI links of a GPU concurrently (a ring all-reduce is bound
-    by one link).  Local HBM traffic on top of that: the packed rows once each way (2 x v P 4 w), nothing else.
+        MAX          2 (N-1)/N 4 P              (ring all-reduce of the radii, 6 MB at P = 1.5 M; hidden behind the backward)
+    At P = 1.5 M, w = 60, v = 0.28, N = 8: 90 MB + 315 MB instead of 2 x 315 MB for the dense all-reduce, and both
+    are all-pairs patterns that use the seven xGMI links of a GPU concurrently (a ring all-reduce is bound by one).
     The result equals the dense all-reduce up to the order of the (at most N) additions per element; with two ranks it
     is bit-identical.  Rows that no rank sees stay exactly zero.
 
@@ -161,42 +165,107 @@ class OwnerReduce:
         self.dev = dev
         self.hip = dev.type == "cuda"
         self.even = self.P == self.world * self.shard  # equal shards: the reduced slices are gathered in place
-        self._counts_host = None
-        self._event = None
-        self._idx = None
-        self._gather = self._acc = None
-        self._edges = torch.tensor([min(d * self.shard, self.P) for d in range(self.world + 1)], dtype=torch.int64, device=dev)
-        if not self.even:  # ragged shards: all_gather of padded shards through a staging buffer
-            self._gather = torch.zeros(self.world * self.shard, self.width, device=dev)
-            self._acc = torch.zeros(self.shard, self.width, device=dev)
         self.rccl = self.hip and dist.get_backend(group) == "nccl"
-        self._coalesce = self.rccl and not os.environ.get("G4S_OWNER_NO_COALESCE")
+        W2 = self.world * self.world
+        with (torch.cuda.device(dev) if self.hip else _nullctx()):
+            # ---- persistent state (LAB_NOTES.md: collectives on persistent buffers only)
+            self._meta = torch.zeros(self.P + W2, dtype=torch.int32, device=dev)  # radii | count matrix [src, dst]
+            self._idx = torch.empty(self.P, dtype=torch.int64, device=dev)
+            self._edges = torch.tensor([min(d * self.shard, self.P) for d in range(self.world + 1)], dtype=torch.int64,
+                                       device=dev)
+            self._counts_host = (torch.zeros(W2, dtype=torch.int32).pin_memory() if self.hip
+                                 else torch.zeros(W2, dtype=torch.int32))
+            self._event = torch.cuda.Event() if self.hip else None
+            self._send = self._recv = None  # float32 [capacity, width + 1], grown on demand (never shrunk)
+            self._gather = self._acc = None
+            if not self.even:  # ragged shards: all_gather of padded shards through a staging buffer
+                self._gather = torch.zeros(self.world * self.shard, self.width, device=dev)
+                self._acc = torch.zeros(self.shard, self.width, device=dev)
+        self._pending = False
+        self._nonzero_static = hasattr(torch, "nonzero_static")
+        # one RCCL group call for the per-tensor in-place gathers: probed ONCE, on a dummy tensor, and agreed on by all
+        # ranks -- a rank that fell back on its own would issue a different collective sequence from its peers
+        self._coalesce = self._probe_coalescing() if (self.rccl and not os.environ.get("G4S_OWNER_NO_COALESCE")) else False
         self.last_rows_sent = None
+        self.allocations = 0  # buffer (re)allocations so far: stays constant once the exchange has warmed up
 
-    def _bounds(self, d):
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def _probe_coalescing(self):
+        ok = 1
+        try:
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            a = torch.zeros(self.world, device=self.dev)
+            b = torch.zeros(self.world, device=self.dev)
+            with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
+                dist.all_gather_into_tensor(a, a[self.rank:self.rank + 1], group=self.group)
+                dist.all_gather_into_tensor(b, b[self.rank:self.rank + 1], group=self.group)
+        except Exception as ex:  # this torch / backend cannot coalesce them
+            import warnings
+            warnings.warn(f"OwnerReduce: coalesced in-place all_gather unavailable ({ex}); one collective per tensor")
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag.item()))
+
+    def bounds(self, d=None):
+        """[lo, hi): the rows owner `d` (default: this rank) holds."""
+        d = self.rank if d is None else d
         return min(d * self.shard, self.P), min((d + 1) * self.shard, self.P)
 
-    def begin(self, visible: torch.Tensor):
-        """`visible`: bool[P], the rows this rank's views can have touched (radii > 0, OR-ed over its views)."""
-        # nonzero_static: fixed-size output (padded with P), so the host does not wait for the count here
-        idx = torch.nonzero_static(visible, size=self.P, fill_value=self.P).view(-1)  # ascending => grouped by owner
-        # per-owner counts: the list is sorted, so owner d's rows are the range between two binary searches (no atomics:
-        # a scatter_add of 1.5 M ones onto 8 counters would serialise on them)
-        pos = torch.searchsorted(idx, self._edges)
-        counts = (pos[1:] - pos[:-1]).contiguous()
-        mat = torch.zeros(self.world, self.world, dtype=torch.int64, device=self.dev)
-        dist.all_gather_into_tensor(mat.view(-1), counts, group=self.group)  # mat[src, dst]
-        self._idx = idx
-        if self.hip:
-            self._counts_host = torch.empty(mat.shape, dtype=mat.dtype, pin_memory=True)
-            self._counts_host.copy_(mat, non_blocking=True)
-            self._event = torch.cuda.Event()
-            self._event.record()
-        else:
-            self._counts_host = mat.clone()
+    _bounds = bounds
+
+    @property
+    def max_radii(self):
+        """int32 [P]: MAX over the ranks of the radii handed to begin() (valid after finish())."""
+        return self._meta[:self.P]
+
+    def _buffer(self, which, rows):
+        buf = getattr(self, which)
+        if buf is None or buf.shape[0] < rows:
+            cap = max(int(rows * 1.25) + 1024, 0 if buf is None else buf.shape[0])
+            with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
+                buf = torch.empty(cap, self.width + 1, device=self.dev)
+            setattr(self, which, buf)
+            self.allocations += 1
+        return buf
+
+    # ---- first half: sizes, overlapped with the backward -----------------------------------------------------------
+    def begin(self, visible: torch.Tensor, radii: Optional[torch.Tensor] = None):
+        """`visible`: bool[P], the rows this rank's views can have touched (radii > 0, OR-ed over its views);
+        `radii`: optional integer [P] tensor whose MAX over the ranks is wanted (max_radii after finish())."""
+        with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
+            # fixed-size index list (padded with P, ascending => grouped by owner): the host does not wait for a count
+            if self._nonzero_static:
+                try:
+                    torch.nonzero_static(visible, size=self.P, fill_value=self.P, out=self._idx.view(self.P, 1))
+                except (TypeError, RuntimeError):
+                    self._idx.copy_(torch.nonzero_static(visible, size=self.P, fill_value=self.P).view(-1))
+            else:  # older torch: nonzero() synchronises on the count
+                nz = visible.nonzero(as_tuple=True)[0]
+                self._idx.fill_(self.P)
+                self._idx[:nz.numel()] = nz
+            # per-owner counts: the list is sorted, so owner d's rows are the range between two binary searches (a
+            # scatter_add of 1.5 M ones onto 8 counters would serialise on them)
+            pos = torch.searchsorted(self._idx, self._edges)
+            meta = self._meta
+            if radii is not None:
+                meta[:self.P].copy_(radii)
+            else:
+                meta[:self.P].zero_()
+            tail = meta[self.P:].view(self.world, self.world)
+            tail.zero_()
+            tail[self.rank].copy_(pos[1:] - pos[:-1])
+            dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.group)  # radii MAX + the count matrix, one collective
+            if self.hip:
+                self._counts_host.copy_(meta[self.P:], non_blocking=True)
+                self._event.record(torch.cuda.current_stream(self.dev))
+            else:
+                self._counts_host.copy_(meta[self.P:])
+        self._pending = True
 
     def _rows_kernel(self, idx, n, buf, mode):
-        """g4s_pack_rows over all row views: mode 2 = pack row-major, 7 = unpack row-major, adding (include/g4s_rasterizer.h)."""
+        """g4s_pack_rows over all row views (include/g4s_rasterizer.h): mode 10 = pack row-major + index column,
+        15 = unpack row-major, adding, indices from the buffer."""
         import ctypes
         from . import _lib
         lib = _lib.load()
@@ -205,89 +274,212 @@ class OwnerReduce:
         widths = (ctypes.c_int * k)(*self.widths)
         with torch.cuda.device(self.dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-            rc = lib.g4s_pack_rows(k, ptrs, widths, ctypes.c_void_p(idx.data_ptr()), int(n),
+            rc = lib.g4s_pack_rows(k, ptrs, widths, ctypes.c_void_p(idx.data_ptr() if idx is not None else 0), int(n),
                                    ctypes.c_void_p(buf.data_ptr()), int(mode), stream)
         if rc != 0:
             raise RuntimeError(f"g4s_pack_rows failed ({rc}): {_lib.last_error()}")
 
-    def _gather_in_place(self, lo, hi):
-        def issue():
-            for r in self.rows:
-                mine = r[lo:hi].reshape(-1)  # a view: rank d's rows of a contiguous [P, w] tensor are contiguous
-                # RCCL gathers in place when the input is the rank's own slot of the output; gloo wants them disjoint
-                dist.all_gather_into_tensor(r.view(-1), mine if self.rccl else mine.clone(), group=self.group)
-        if self._coalesce:
-            try:  # one RCCL group call for the per-tensor gathers
-                from torch.distributed.distributed_c10d import _coalescing_manager
-                with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
-                    issue()
-                return
-            except (ImportError, RuntimeError, TypeError, NotImplementedError) as ex:
-                self._coalesce = False  # this torch / backend cannot coalesce them: one collective per tensor
-                import warnings
-                warnings.warn(f"OwnerReduce: coalesced in-place all_gather unavailable ({ex}); issuing one collective per tensor")
-        issue()
+    def all_gather_rows(self, tensors: Sequence[torch.Tensor]):
+        """All-gathers the owners' row ranges of contiguous [P, ...] tensors in place (equal shards), as one RCCL group
+        where the backend can: on return every rank holds every owner's rows."""
+        lo, hi = self.bounds()
+        if not self.even:
+            for t in tensors:  # ragged: padded staging buffer per tensor
+                w = t[0].numel() if t.ndim > 1 else 1
+                flat = t.view(self.P, w)
+                stage = torch.zeros(self.world * self.shard, w, dtype=t.dtype, device=t.device)
+                mine = torch.zeros(self.shard, w, dtype=t.dtype, device=t.device)
+                mine[:hi - lo] = flat[lo:hi]
+                dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self.group)
+                flat.copy_(stage[:self.P])
+            return
 
-    def finish(self):
-        """Reduces the rows in place: on return every row view holds the sum over all ranks."""
+        def issue():
+            for t in tensors:
+                mine = t[lo:hi].reshape(-1)  # a view: rank d's rows of a contiguous [P, w] tensor are contiguous
+                # RCCL gathers in place when the input is the rank's own slot of the output; gloo wants them disjoint
+                dist.all_gather_into_tensor(t.view(-1), mine if self.rccl else mine.clone(), group=self.group)
+        if self._coalesce:
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
+                issue()
+        else:
+            issue()
+
+    # ---- second half: rows to their owners, owners accumulate, (optionally) everybody gets every shard ------------
+    def finish(self, gather: bool = True):
+        """Reduces the rows in place.  gather=True: on return every row view holds the sum over all ranks.
+        gather=False: only this rank's own rows [bounds()) do (what an owner-applied optimiser needs)."""
+        if not self._pending:
+            raise RuntimeError("OwnerReduce.finish() without begin()")
+        self._pending = False
         if self._event is not None:
             self._event.synchronize()  # recorded a whole backward ago: returns at once
-            self._event = None
-        mat = self._counts_host.tolist()
+        mat = self._counts_host.view(self.world, self.world).tolist()
         send = [int(x) for x in mat[self.rank]]
         recv = [int(mat[s][self.rank]) for s in range(self.world)]
         # rows this rank owns itself stay where they are: they are neither packed nor sent
         a = sum(send[:self.rank])
         b = a + send[self.rank]
-        self.last_rows_sent = sum(send) - send[self.rank]
-        idx = torch.cat((self._idx[:a], self._idx[b:sum(send)]))
+        total = sum(send)
+        self.last_rows_sent = total - send[self.rank]
         send[self.rank] = 0
         recv[self.rank] = 0
         n, m = sum(send), sum(recv)
-        # pack my visible rows, [n, width] row-major: the rows for owner d are one contiguous range
-        out_rows = torch.empty(n, self.width, device=self.dev)
-        if self.hip:
-            if n:
-                self._rows_kernel(idx, n, out_rows, 2)
-        else:
+        W = self.width
+        with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
+            out_rows = self._buffer("_send", n)[:n]
+            in_rows = self._buffer("_recv", m)[:m]
+            # pack my visible rows, [n, width + 1] row-major: the rows for owner d are one contiguous range, and the
+            # last column carries the row index (int32 bits), so rows and indices travel in ONE all_to_all
+            if self.hip:
+                if a:
+                    self._rows_kernel(self._idx[:a], a, out_rows[:a], 10)
+                if total - b:
+                    self._rows_kernel(self._idx[b:total], total - b, out_rows[a:], 10)
+            else:
+                idx = torch.cat((self._idx[:a], self._idx[b:total]))
+                off = 0
+                for r, w in zip(self.rows, self.widths):
+                    out_rows[:, off:off + w] = r.index_select(0, idx)
+                    off += w
+                out_rows[:, W] = idx.to(torch.int32).view(torch.float32)
+            dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
+            # owner: my own contribution already sits in my slice; add the other ranks' rows to it, source by source (a
+            # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
+            o = 0
+            for s_ in range(self.world):
+                c = recv[s_]
+                if c:
+                    if self.hip:
+                        self._rows_kernel(None, c, in_rows[o:o + c], 15)
+                    else:
+                        ridx = in_rows[o:o + c, W].contiguous().view(torch.int32).to(torch.int64)
+                        off = 0
+                        for r, w in zip(self.rows, self.widths):
+                            r.index_add_(0, ridx, in_rows[o:o + c, off:off + w])
+                            off += w
+                o += c
+            if not gather:
+                return
+            # every rank gets every reduced shard
+            lo, hi = self.bounds()
+            if self.even:
+                self.all_gather_rows(self.rows)
+                return
             off = 0
             for r, w in zip(self.rows, self.widths):
-                out_rows[:, off:off + w] = r.index_select(0, idx)
+                self._acc[:hi - lo, off:off + w] = r[lo:hi]
                 off += w
-        in_rows = torch.empty(m, self.width, device=self.dev)
-        in_idx = torch.empty(m, dtype=torch.int64, device=self.dev)
-        dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
-        dist.all_to_all_single(in_idx, idx, recv, send, group=self.group)
-        # owner: my own contribution already sits in my slice; add the other ranks' rows to it, source by source (a
-        # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
-        o = 0
-        for s in range(self.world):
-            c = recv[s]
-            if c:
-                if self.hip:
-                    self._rows_kernel(in_idx[o:o + c], c, in_rows[o:o + c], 7)
-                else:
-                    off = 0
-                    for r, w in zip(self.rows, self.widths):
-                        r.index_add_(0, in_idx[o:o + c], in_rows[o:o + c, off:off + w])
-                        off += w
-            o += c
-        # every rank gets every reduced shard
-        lo, hi = self._bounds(self.rank)
-        if self.even:
-            self._gather_in_place(lo, hi)
-            return
-        off = 0
-        for r, w in zip(self.rows, self.widths):
-            self._acc[:hi - lo, off:off + w] = r[lo:hi]
-            off += w
-        dist.all_gather_into_tensor(self._gather.view(-1), self._acc.view(-1), group=self.group)
-        full = self._gather[:self.P]
-        # (shards are padded to `shard` rows: rank d's rows sit at [d * shard, d * shard + (hi_d - lo_d)) = their global index)
-        off = 0
-        for r, w in zip(self.rows, self.widths):
-            r.copy_(full[:, off:off + w])
-            off += w
+            dist.all_gather_into_tensor(self._gather.view(-1), self._acc.view(-1), group=self.group)
+            full = self._gather[:self.P]
+            # (shards are padded to `shard` rows: rank d's rows sit at [d * shard, d * shard + (hi_d - lo_d)) = their global index)
+            off = 0
+            for r, w in zip(self.rows, self.widths):
+                r.copy_(full[:, off:off + w])
+                off += w
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def adam_update_(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-15):
+    """Plain Adam on host tensors, element by element what csrc/loss.hip's adam_kernel computes (torch.optim.Adam's
+    single-tensor formula): used by ShardedAdam on CPU (gloo tests) -- on a HIP device the kernel itself runs."""
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    m.add_((g - m) * float(1.0 - beta1))
+    v.mul_(float(beta2)).add_(g * g * float(1.0 - beta2))
+    denom = v.sqrt() * float(1.0 / (bc2 ** 0.5)) + float(eps)
+    p.sub_((m / denom) * float(lr / bc1))
+
+
+class ShardedAdam:
+    """Owner-applied Adam behind OwnerReduce (ZeRO-1).
+
+    After `reducer.finish(gather=False)` rank d holds the fully reduced gradient of its own rows only.  It applies Adam
+    to THOSE rows of the replicated parameters -- optimiser state (exp_avg, exp_avg_sq) exists for the rank's shard
+    only: 2 x 232 B per Gaussian / N instead of per rank -- and the all_gather that would have carried 58 gradient
+    floats per row carries the 58 updated parameter floats instead (same bytes, optimiser work / N).  Adam is
+    element-wise, so the parameters equal the replicated optimiser's bit for bit (tests/test_dp_gloo.py).
+
+        red = OwnerReduce(grad_row_views + [side]);  opt = ShardedAdam(params, grad_row_views, red, lrs, eps=1e-15)
+        red.begin(visible, radii); ...backward...; red.finish(gather=False); opt.step(extra=[side])
+
+    `params[i]` and `grads[i]` are contiguous float32 [P, ...] tensors; `extra` tensors ([P, ...], e.g. the
+    densification statistics, reduced like the gradients) are gathered alongside the parameters.
+    Densification changes P and with it the shard boundaries: `full_state()` returns the all-gathered state for the
+    (replicated) row edits and `load_full_state()` re-shards it."""
+
+    def __init__(self, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], reducer: OwnerReduce,
+                 lrs: Sequence[float], betas=(0.9, 0.999), eps: float = 1e-15):
+        self.params, self.grads, self.red = list(params), list(grads), reducer
+        self.lrs, self.betas, self.eps = [float(x) for x in lrs], (float(betas[0]), float(betas[1])), float(eps)
+        if len(self.params) != len(self.grads) or len(self.params) != len(self.lrs) or not 1 <= len(self.params) <= 8:
+            raise ValueError("ShardedAdam: 1..8 parameters, one gradient tensor and one learning rate each")
+        lo, hi = reducer.bounds()
+        for p, g in zip(self.params, self.grads):
+            if p.shape != g.shape or p.shape[0] != reducer.P or not p.is_contiguous() or not g.is_contiguous() \
+                    or p.dtype != torch.float32:
+                raise ValueError("ShardedAdam: parameters and gradients must be contiguous float32 [P, ...] tensors")
+        self.exp_avg = [torch.zeros_like(p[lo:hi]) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p[lo:hi]) for p in self.params]
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, lrs: Optional[Sequence[float]] = None, extra: Sequence[torch.Tensor] = ()):
+        if lrs is not None:
+            self.lrs = [float(x) for x in lrs]
+        self.steps += 1
+        lo, hi = self.red.bounds()
+        ps = [p.data[lo:hi] for p in self.params]
+        gs = [g[lo:hi] for g in self.grads]
+        if hi > lo:
+            if self.red.hip:
+                import ctypes
+                from . import _lib
+                lib = _lib.load()
+                k = len(ps)
+                ptr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+                with torch.cuda.device(self.red.dev):
+                    stream = ctypes.c_void_p(torch.cuda.current_stream(self.red.dev).cuda_stream)
+                    rc = lib.g4s_adam_step(k, ptr(ps), ptr(gs), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                           (ctypes.c_longlong * k)(*[t.numel() for t in ps]),
+                                           (ctypes.c_double * k)(*self.lrs), (ctypes.c_int * k)(*([self.steps] * k)),
+                                           self.betas[0], self.betas[1], self.eps, stream)
+                if rc != 0:
+                    raise RuntimeError(f"g4s_adam_step failed ({rc}): {_lib.last_error()}")
+            else:
+                for p, g, m, v, lr in zip(ps, gs, self.exp_avg, self.exp_avg_sq, self.lrs):
+                    adam_update_(p, g, m, v, lr, self.steps, self.betas[0], self.betas[1], self.eps)
+        self.red.all_gather_rows([p.data for p in self.params] + list(extra))
+
+    @torch.no_grad()
+    def full_state(self):
+        """-> (exp_avg, exp_avg_sq) lists of full [P, ...] tensors (all-gathered), for row edits at densification."""
+        out = []
+        lo, hi = self.red.bounds()
+        for part in (self.exp_avg, self.exp_avg_sq):
+            full = [torch.zeros_like(p.data) for p in self.params]
+            for f, s_ in zip(full, part):
+                f[lo:hi] = s_
+            self.red.all_gather_rows(full)
+            out.append(full)
+        return out[0], out[1]
+
+    @torch.no_grad()
+    def load_full_state(self, params, grads, reducer, exp_avg, exp_avg_sq):
+        """Re-shards after a densification: new parameter / gradient tensors, a reducer built for the new P, and the
+        edited full state tensors."""
+        self.params, self.grads, self.red = list(params), list(grads), reducer
+        lo, hi = reducer.bounds()
+        self.exp_avg = [t[lo:hi].clone() for t in exp_avg]
+        self.exp_avg_sq = [t[lo:hi].clone() for t in exp_avg_sq]
 
 
 class ViewParallel:
@@ -342,9 +534,11 @@ class ViewParallel:
             self._side[:, 0:1] = self.grad_norm_sum
             self._side[:, 1:2] = self.vis_count
             vis = self._visible if self._visible is not None else torch.zeros(P, dtype=torch.bool, device=self._side.device)
-            self._owner.begin(vis)   # (a training loop calls begin() right after its forward; here both halves run back to back)
+            # (a training loop that drives OwnerReduce itself calls begin() right after its forward, so that the size
+            # exchange hides behind the backward -- bench.py does; here both halves run back to back)
+            self._owner.begin(vis, radii=self.max_radii.to(torch.int32))  # the radii MAX rides in the same collective
             self._owner.finish()
-            dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=self.group)
+            self.max_radii = self._owner.max_radii.to(self.max_radii.dtype)
             self.grad_norm_sum, self.vis_count = self._side[:, 0:1].clone(), self._side[:, 1:2].clone()
         elif dist.is_initialized() and self.world_size > 1:
             dist.all_reduce(self.max_radii, op=dist.ReduceOp.MAX, group=self.group)

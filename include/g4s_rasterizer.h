@@ -244,6 +244,9 @@ int g4s_get_option(const char* name, int* value);
  *   bit 1   buffer layout: 0 = segment after segment (packed = [n*widths[0] | n*widths[1] | ...]),
  *           1 = row-major [n, sum(widths)] (row ranges of the buffer are contiguous: all_to_all splits)
  *   bit 2   unpack adds to the rows instead of overwriting them (indices must be distinct)
+ *   bit 3   (row-major only) a buffer row is sum(widths) + 1 floats: the last one carries the row's index as int32
+ *           bits -- pack writes it, unpack reads it INSTEAD of `row_index` (which may be NULL then): rows and their
+ *           indices travel in one all_to_all
  * `segments` / `widths` are HOST arrays of device pointers / ints; `row_index` is a device int64 array.
  */
 int g4s_pack_rows(int nseg, float* const* segments, const int* widths, const long long* row_index, int n,

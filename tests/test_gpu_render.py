@@ -189,6 +189,22 @@ def test_pack_rows_roundtrip(hip_lib):
         assert bool((s[idx] == 1.5).all()) and torch.equal(s[keep], b[keep])
     assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
                                  ctypes.c_void_p(rm.data_ptr()), 4, stream) < 0  # add without unpack
+    # mode bit 3: a trailing int32 index column -- rows and their indices travel in ONE all_to_all (OwnerReduce): pack
+    # writes it, the accumulating unpack reads the row indices from the buffer (row_index = NULL)
+    W = sum(widths)
+    rc = torch.full((n, W + 1), float("nan"), device="cuda:0")
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, ctypes.c_void_p(idx.data_ptr()), n,
+                                 ctypes.c_void_p(rc.data_ptr()), 10, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(rc[:, :W], torch.cat([s.index_select(0, idx) for s in segs], dim=1))
+    assert torch.equal(rc[:, W].contiguous().view(torch.int32).to(torch.int64), idx)
+    before = [s.clone() for s in segs]
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, None, n, ctypes.c_void_p(rc.data_ptr()), 15, stream) == 0
+    torch.cuda.synchronize()
+    for s, b in zip(segs, before):
+        assert torch.equal(s[idx], b[idx] + b[idx]) and torch.equal(s[keep], b[keep])
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, None, n, ctypes.c_void_p(rc.data_ptr()), 9, stream) < 0  # needs row-major
+    assert hip_lib.g4s_pack_rows(len(segs), ptrs, wid, None, n, ctypes.c_void_p(rc.data_ptr()), 10, stream) < 0  # pack needs idx
 
 
 @pytest.mark.parametrize("D,M", [(3, 16), (1, 16), (0, 16), (2, 9), (0, 1)])

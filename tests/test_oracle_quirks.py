@@ -132,3 +132,25 @@ def test_median_contributor_bookkeeping(oracle_mod):
 def test_higher_msb(oracle_mod):
     for n, want in ((1, 1), (2, 2), (117, 7), (256, 9), (7500, 13), (65535, 16)):
         assert oracle_mod.get_higher_msb(n) == want
+
+
+def test_backward_is_a_sum_of_per_pixel_contributions(oracle_mod):
+    """What the parity gate's masked re-run relies on (tests/common.py): the backward is linear in the cotangents and a
+    pixel's contribution depends on that pixel's cotangents only -- zeroing the cotangents of a pixel set removes
+    exactly that set's contribution, and the oracle object can run several backwards over one forward."""
+    from common import cotangents, run_oracle, scene_inputs
+    inp = scene_inputs(P=400, W=48, H=40, seed=5, D=2)
+    g = cotangents(40, 48, seed=2)
+    o = run_oracle(oracle_mod, inp, g)
+    rng = np.random.default_rng(0)
+    mask = rng.random((40, 48)) < 0.3
+    ga = (np.where(mask, 0, g[0]).astype(np.float32), np.where(mask, 0, g[1]).astype(np.float32))
+    gb = (np.where(mask, g[0], 0).astype(np.float32), np.where(mask, g[1], 0).astype(np.float32))
+    a = o["oracle"].rasterize_gaussians_backward(*ga)
+    b = o["oracle"].rasterize_gaussians_backward(*gb)
+    again = o["oracle"].rasterize_gaussians_backward(*g)
+    for k in o["grads"]:
+        np.testing.assert_array_equal(again[k], o["grads"][k])
+        full = o["grads"][k].astype(np.float64)
+        np.testing.assert_allclose(a[k].astype(np.float64) + b[k].astype(np.float64), full,
+                                   atol=2e-5 * (np.abs(full).max() + 1e-30), rtol=0)

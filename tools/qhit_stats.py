@@ -60,8 +60,8 @@ for t in tiles:
     if len(q) & 1:
         q = np.concatenate([q, [0]])
     a, b = q[0::2], q[1::2]
-    both += int(np.unpackbits((a & b)[:, None], axis=1).sum())
-    one += int(np.unpackbits((a ^ b)[:, None], axis=1).sum())
-    vis_s += int(np.unpackbits(q[:, None], axis=1).sum())
+    both += int(np.unpackbits((a & b).astype(np.uint8)[:, None], axis=1).sum())
+    one += int(np.unpackbits((a ^ b).astype(np.uint8)[:, None], axis=1).sum())
+    vis_s += int(np.unpackbits(q.astype(np.uint8)[:, None], axis=1).sum())
 print("entry pairs (sample of %d tiles): quadrant visits %d -> packed %d (cover %.1f %%), single %d" %
       (len(tiles), vis_s, both, 200.0 * both / max(vis_s, 1), one))
