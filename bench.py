@@ -276,11 +276,20 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_s, units_s = 0, 0
-        # (every rank runs the same number of steps: the count is fixed up front from the headline's step time)
-        n_target = max(500, int(math.ceil(args.sustained_seconds / max(elapsed / args.steps, 1e-6))))
-        for i in range(n_target):
-            step(i)
-            units_s += Vs[(rank + i * world) % len(dcams)]
+        # every rank must run the same number of steps (each one holds collectives): the count comes from the slowest
+        # rank's headline time; the pass repeats the headline's K steps (same views) over and over
+        el = elapsed
+        if dist is not None:
+            tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        n_target = max(500, int(math.ceil(args.sustained_seconds / max(el / args.steps, 1e-6))))
+        marks = []  # host time every 50 steps: the reference-shaped forward waits for its read-back, so the host runs at
+        for i in range(n_target):   # most one step ahead of the GPU and these times follow the GPU's progress
+            if i % 50 == 0:
+                marks.append(time.perf_counter())
+            step(i % args.steps)
+            units_s += Vs[(rank + (i % args.steps) * world) % len(dcams)]
             n_s += 1
             if rank == 0 and i in (n_target // 2, (3 * n_target) // 4, n_target - 1):
                 mhz = read_sclk_mhz(local_rank)
@@ -301,8 +310,10 @@ def main():
         sustained = {"steps": n_s, "seconds": round(dt_s, 3), "ms_per_step": round(dt_s / n_s * 1e3, 4),
                      "value": units_s / dt_s, "unit": "Gaussians/s",
                      "effective_clock_GHz": (round(sum(sclk) / len(sclk) / 1e3, 3) if sclk else None),
-                     "clock_source": ("sysfs pp_dpm_sclk sampled at 1/2, 3/4 and the end of the pass" if sclk else
+                     "clock_source": ("sysfs pp_dpm_sclk (the DPM level in force, not a cycle count) sampled at 1/2, 3/4 and "
+                                      "the end of the pass" if sclk else
                                       "sysfs pp_dpm_sclk not readable on this box"),
+                     "ms_per_step_by_50_steps": [round((b - a) / 50 * 1e3, 4) for a, b in zip(marks, marks[1:])],
                      "note": "same step as the headline, issued back to back right behind it (no pause)"}
 
     exchange_ms = None

@@ -126,7 +126,7 @@ struct ProfScope {
 };
 
 // Bits of the tile field the partition sorts on: the reference's getHigherMsb(tiles) (rasterizer_impl.cu:301), capped
-// at the 16 bits the field has -- for exactly 65 536 tiles getHigherMsb says 17, which would shift a 64-bit key by 64.
+// at the 32 bits the field has.
 uint32_t higher_msb(uint32_t n) {  // rasterizer_impl.cu:35-50
     uint32_t msb = sizeof(n) * 4, step = msb;
     while (step > 1) {
@@ -138,7 +138,7 @@ uint32_t higher_msb(uint32_t n) {  // rasterizer_impl.cu:35-50
 }
 int tile_sort_bits(int tiles) {
     const int b = (int)higher_msb((uint32_t)tiles);
-    return b < 16 ? b : 16;
+    return b < 32 ? b : 32;
 }
 
 }  // namespace
@@ -246,8 +246,10 @@ static int rasterizer_forward_impl(
     if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_others)
         return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
     const int tiles_x = (width + TILE - 1) / TILE, tiles_y = (height + TILE - 1) / TILE;
+    // (tile coordinates travel in 16 bits each -- the binned rect of a Gaussian -- and the tile id in 32)
+    if (tiles_x > 65535 || tiles_y > 65535 || (long long)tiles_x * tiles_y > 0x7FFFFFFFll)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "image too large: %d x %d tiles (at most 65535 per axis)", tiles_x, tiles_y);
     const int tiles = tiles_x * tiles_y;
-    if (tiles > 65536) return fail(G4S_ERR_INVALID_ARGUMENT, "image too large: %d tiles > 65536", tiles);
     const size_t N = (size_t)width * height;
 
     // image chunk first: with P == 0 the frame is still background (rasterize_points.cu:85-99
@@ -484,9 +486,9 @@ extern "C" int g4s_rasterizer_forward_presized(
 }
 
 extern "C" size_t g4s_rasterizer_backward_workspace(int P, int R) {
-    // gradient records | deep-tile counter + list   (the records' validity bytes live in the forward's binning chunk)
+    // gradient records   (their validity bytes live in the forward's binning chunk, the deep-tile list in its image chunk)
     (void)P;
-    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + 256 + 65536 * 4 + 256;
+    return align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4) + 256;
 }
 
 static int rasterizer_backward_impl(
@@ -526,9 +528,9 @@ static int rasterizer_backward_impl(
 
     // gradient records: only instances that receive a contribution are written by the blend backward; instead of
     // clearing 80 B per instance, one validity byte per instance is cleared and the fold selects on it
-    // the deep-tile counter + list sit behind the records; the counter is cleared by the tile-order kernel below
-    uint32_t* hot_count = (uint32_t*)((char*)grad_inst + align_up((size_t)(R > 0 ? R : 1) * GRAD_STRIDE * 4));
-    uint32_t* hot_list = hot_count + 64;
+    // the deep-tile counter + list sit in the image chunk; the counter is cleared by the tile-order kernel below
+    uint32_t* hot_count = (uint32_t*)(img + IL.hot_count);
+    uint32_t* hot_list = (uint32_t*)(img + IL.hot_list);
     // One validity byte per record slot says which records the blend backward wrote; the bytes live in the binning chunk
     // and were cleared by the forward (emit).  A second backward over the same forward state finds them set -- to the
     // values it is going to write again (which records are written depends on the forward's state only).
@@ -551,6 +553,7 @@ static int rasterizer_backward_impl(
         bb.final_T = (const float*)(img + IL.final_T);
         bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
+        bb.tight_rect = (const uint2*)(geom + GL.tight_rect);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
         bb.n_slots = (uint32_t)R;
         bb.no_fastpath = opt(OPT_NO_FASTPATH) != 0;

@@ -8,7 +8,7 @@
 // MI355X design (not the reference's 64-bit-key sort over all R instances):
 //   1. sort the Gaussians that emit instances once by depth bits (32-bit keys, stable => ties by index),
 //   2. emit instances in that order with a load-balanced expansion partitioned by OUTPUT slots (coalesced
-//      8-byte stores), packed as  tile<<48 | k<<32 | gaussian   (k = instance number inside the Gaussian),
+//      8-byte stores), packed as  tile<<32 | gaussian  (the instance number k inside the Gaussian only picks the tile),
 //   3. stable radix partition on the tile bits only (2 passes instead of 6).
 // A stable partition of a depth-ordered sequence yields exactly the reference's per-tile order.
 // Radix passes: a workgroup of four waves owns a block of keys, every wave ranks its contiguous share with ballot
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tile
         const uint32_t rx0 = s_rect[a] & 0xFFFFu, ry0 = s_rect[a] >> 16;
         const uint32_t ty = k / w, tx = k - ty * w;
         const uint64_t tile = (uint64_t)((ry0 + ty) * (uint32_t)tiles_x + rx0 + tx);
-        entries[o] = (tile << ENTRY_TILE_SHIFT) | ((uint64_t)k << ENTRY_K_SHIFT) | (uint64_t)s_idx[a];
+        entries[o] = (tile << ENTRY_TILE_SHIFT) | (uint64_t)s_idx[a];
     }
 }
 

@@ -366,7 +366,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
             nolp_l = !a.no_fastpath && (__float_as_uint(q0.w) & REC_NO_LOWPASS) != 0;
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
-            s_slot[lane] = __float_as_uint(q0.z) + entry_k(e);
+            s_slot[lane] = __float_as_uint(q0.z) + instance_number(a.tight_rect[entry_idx(e)], (uint32_t)tile_x, (uint32_t)tile_y);
         }
         __syncthreads();
 
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     if (!a.no_fastpath && (__float_as_uint(rq[0].w) & REC_NO_LOWPASS)) qmask |= 16u;
 #pragma unroll
                     for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
-                    s_slot[lane] = __float_as_uint(rq[0].z) + entry_k(e);
+                    s_slot[lane] = __float_as_uint(rq[0].z) + instance_number(a.tight_rect[entry_idx(e)], (uint32_t)tile_x, (uint32_t)tile_y);
                 }
                 s_q[lane] = qmask;
             }

@@ -34,14 +34,18 @@ constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 constexpr int SORT_ITEMS_U32 = G4S_SORT_ITEMS_U32;  // depth sort of the emitting Gaussians (32-bit keys + index)
 constexpr int SORT_ITEMS_U64 = G4S_SORT_ITEMS_U64;  // tile partition of the packed instances
 inline size_t sort_blocks(size_t n, int items) { return (n + (size_t)256 * items - 1) / ((size_t)256 * items); }
-// Packed instance: bits 63..48 tile id, 47..32 k (instance number inside its Gaussian, < #tiles
-// <= 65536), 31..0 Gaussian index.  Every field sits on a natural 16/32-bit boundary on purpose:
-// hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load and then drops the mask.
-constexpr int ENTRY_TILE_SHIFT = 48;
-constexpr int ENTRY_K_SHIFT = 32;
+// Packed instance: bits 63..32 tile id, 31..0 Gaussian index -- the reference's key without the depth bits
+// (rasterizer_impl.cu:102-103 keeps the tile id in the upper word too), so any frame the reference can render fits.
+// Both fields sit on a 32-bit boundary on purpose: hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load
+// and then drops the mask.  The instance number k of an entry inside its Gaussian (= its gradient-record slot minus
+// inst_off) is not stored: the backward recomputes it from the tile and the Gaussian's binned tile rect.
+constexpr int ENTRY_TILE_SHIFT = 32;
 __host__ __device__ inline uint32_t entry_idx(uint64_t e) { return (uint32_t)e; }
-__host__ __device__ inline uint32_t entry_k(uint64_t e) { return (uint32_t)(e >> ENTRY_K_SHIFT) & 0xFFFFu; }
 __host__ __device__ inline uint32_t entry_tile(uint64_t e) { return (uint32_t)(e >> ENTRY_TILE_SHIFT); }
+// tight_rect = (x0 | y0 << 16, width in tiles) of the rect a Gaussian is binned into (row-major instance numbering)
+__host__ __device__ inline uint32_t instance_number(uint2 tight_rect, uint32_t tile_x, uint32_t tile_y) {
+    return (tile_y - (tight_rect.x >> 16)) * tight_rect.y + (tile_x - (tight_rect.x & 0xFFFFu));
+}
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -56,7 +60,7 @@ struct BinLayout {
     size_t ent_a, ent_b, hist, bin_total, qhit, rec_flag, bytes;
 };
 struct ImgLayout {
-    size_t ranges, final_T, n_contrib, tile_order, tile_depth, tile_order_bwd, bytes;
+    size_t ranges, final_T, n_contrib, tile_order, tile_depth, tile_order_bwd, hot_count, hot_list, bytes;
 };
 
 inline GeomLayout geom_layout(size_t P) {
@@ -112,6 +116,8 @@ inline ImgLayout img_layout(size_t N, size_t tiles) {
     L.tile_order = take(tiles * 4);
     L.tile_depth = take(tiles * 8);      // (0, deepest last contributor) per tile, written by the blend forward
     L.tile_order_bwd = take(tiles * 4);  // processing order of the backward: deepest live list first
+    L.hot_count = take(256);             // the backward's deep-tile counter ...
+    L.hot_list = take(tiles * 4);        // ... and list (blend_bwd_hot_kernel)
     L.bytes = o + 256;
     return L;
 }
@@ -202,6 +208,7 @@ struct BlendBwdArgs {
     const float* final_T;
     const uint32_t* n_contrib;
     const uint8_t* qhit;
+    const uint2* tight_rect;  // per Gaussian: the binned tile rect (gives an entry's instance number = record slot - inst_off)
     const float* dL_dpix;
     const float* dL_depths;
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so

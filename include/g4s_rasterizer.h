@@ -70,7 +70,7 @@ const char* g4s_version(void);
  * reference's) or a negative G4S_ERR_*.  Contains ONE host synchronisation (reading
  * num_rendered to size the binning chunk), exactly like the reference
  * (rasterizer_impl.cu:281-282).
- * Limit: ceil(W/16)*ceil(H/16) <= 65536 tiles.
+ * Limit: at most 65535 tiles (1 048 560 pixels) per axis.
  */
 int g4s_rasterizer_forward(
     g4s_resize_fn geometry_buffer, void* geometry_ctx,
@@ -209,7 +209,7 @@ typedef struct g4s_layout {
     size_t tiles_touched;/* P x u32 */
     size_t geom_bytes;
     /* binning chunk */
-    size_t entries;      /* R x u64 sorted instances: tile<<48 | k<<32 | idx */
+    size_t entries;      /* R x u64 sorted instances: tile<<32 | idx */
     size_t qhit;         /* one byte per sorted instance: bit q = quadrant q of its tile blended it */
     size_t binning_bytes;
     /* image chunk */

@@ -27,7 +27,7 @@ def check_lists_against_oracle(st, orc, oracle_mod):
     flags = oracle_mod.instance_flags(orc)
     ent = st["entries"]
     counts = (st["ranges"][:, 1] - st["ranges"][:, 0]).astype(np.int64)
-    assert np.array_equal((ent >> np.uint64(48)).astype(np.int64), np.repeat(np.arange(len(counts)), counts))
+    assert np.array_equal((ent >> np.uint64(32)).astype(np.int64), np.repeat(np.arange(len(counts)), counts))
     kept = 0
     for tile, hl in enumerate(hip_tile_lists(st)):
         ol = olist[orng[tile, 0]:orng[tile, 1]]
@@ -542,22 +542,26 @@ def test_hair_thin_splat_found_by_the_fuzz_sweep(hip_lib, oracle_mod):
     assert_parity(h, o, inp, oracle_mod)
 
 
-def test_largest_tile_grid(hip_lib, oracle_mod):
-    """4096 x 4096 = 65 536 tiles, the documented limit (16-bit tile ids): forward + backward against the oracle, and one
-    pixel more in either direction is refused with an error instead of overflowing."""
-    import torch
-    from g4splat_amd.diff_surfel_rasterization import _C
-    inp = scene_inputs(P=3000, W=4096, H=4096, seed=91, D=1, scale_mul=1.5)
-    g = cotangents(4096, 4096, seed=6)
+@pytest.mark.parametrize("side", [4096, 4112])
+def test_largest_tile_grids(hip_lib, oracle_mod, side):
+    """4096 x 4096 = 65 536 tiles (round 2's limit: 16-bit tile ids) and 4112 x 4112 = 66 049 tiles, beyond it: the
+    instance key now carries the tile id in its upper 32 bits like the reference's (rasterizer_impl.cu:102-103), so
+    such frames render -- forward + backward against the oracle with the same proof as at the metric's size
+    (~10^9 pixel-splat evaluations).  Only frames with more than 65 535 tiles along one axis are refused."""
+    inp = scene_inputs(P=3000, W=side, H=side, seed=91, D=1, scale_mul=1.5)
+    g = cotangents(side, side, seed=6)
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
-    # ~10^9 (pixel, splat) evaluations: the same proof as at the metric's size
-    assert_parity(h, o, inp, oracle_mod, tag="4096x4096")
+    assert_parity(h, o, inp, oracle_mod, tag=f"{side}x{side}")
     assert np.median(np.abs(h["color"] - o["color"])) <= 1e-6
-    big = dict(inp)
-    big["W"] = 4097
-    with pytest.raises(RuntimeError, match="tiles"):
-        run_hip(big)
+    if side > 4096:
+        st = hip_state(h, inp)
+        assert int((st["entries"] >> np.uint64(32)).max()) >= 65536  # tile ids beyond 16 bits are in use
+        big = dict(inp, W=16 * 65536, H=16)  # 65 536 tiles in one row: one more than a 16-bit tile coordinate holds
+        with pytest.raises(RuntimeError, match="tiles"):
+            run_hip(big)
+        ok = run_hip(dict(inp, W=16 * 65535, H=16))  # 65 535 x 1 tiles: the widest frame there is
+        assert ok["color"].shape == (3, 16, 16 * 65535)
 
 
 def test_presized_forward_never_blocks_the_host_and_matches(hip_lib):

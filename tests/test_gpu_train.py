@@ -244,3 +244,121 @@ def test_config3_densify_and_prune_schedule_at_metric_size(hip_lib, capsys):
         print(f"\nC3 schedule at 1.5 M: sizes {sizes} -> {n}, loss {losses[0]:.4f} -> {losses[-1]:.4f}, PSNR {psnr0:.2f} -> {psnr1:.2f} dB, "
               f"{dt / 300 * 1e3:.2f} ms per iteration incl. densification")
     assert psnr1 > psnr0 + 1.0, (psnr0, psnr1)
+
+
+def _densify_state(P, dev, seed=11):
+    """A room-scene model at size P with optimiser moments and densification statistics arranged so that ONE
+    densify_and_prune clones, splits and prunes a material share of the rows (>= 5 % each)."""
+    import types
+    scene = synthetic.scene_room(P, seed=0)
+    rng = np.random.default_rng(seed)
+    m = GaussianModel(3)
+    cols = np.clip(scene.shs[:, 0, :] * 0.28209479177387814 + 0.5, 0, 1).astype(np.float32)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    m.create_from_parameters(t(scene.means3D), t(scene.scales), t(scene.rotations), t(cols), 1.0)
+    with torch.no_grad():
+        op = np.clip(scene.opacities, 1e-4, 1 - 1e-4).astype(np.float32)
+        op[rng.random(P) < 0.08] = 0.02            # 8 % below min_opacity = 0.05: pruned
+        m._opacity.copy_(t(np.log(op / (1 - op))))
+        sc = scene.scales.copy()
+        big = rng.random(P) < 0.5                   # half the rows above percent_dense * extent = 0.06: split candidates
+        sc[big] = rng.uniform(0.07, 0.09, (int(big.sum()), 2)).astype(np.float32)
+        sc[~big] = np.minimum(sc[~big], 0.05)
+        m._scaling.copy_(t(np.log(sc)))
+        m._features_rest.copy_(t(scene.shs[:, 1:, :]))
+    m.training_setup()
+    # moments as after a few Adam steps, statistics as after a few views: ~14 % of the rows above the threshold
+    for p_ in m.parameters():
+        st = m.optimizer.state[p_]
+        st["step"] = torch.tensor(3.0)
+        st["exp_avg"] = t(rng.normal(0, 1e-3, tuple(p_.shape)).astype(np.float32))
+        st["exp_avg_sq"] = t(rng.uniform(0, 1e-6, tuple(p_.shape)).astype(np.float32))
+    m.denom = t(rng.integers(0, 4, (P, 1)).astype(np.float32))            # zeros included: NaN statistics (0 / 0)
+    m.xyz_gradient_accum = t((rng.random((P, 1)) < 0.14).astype(np.float32) * 1e-3) * torch.clamp(m.denom, min=1.0)
+    m.max_radii2D = t(rng.uniform(0, 30, P).astype(np.float32))           # some beyond the screen-size limit of 20
+    return m
+
+
+def _snapshot(m):
+    out = {}
+    for name, p_ in (("xyz", m._xyz), ("f_dc", m._features_dc), ("f_rest", m._features_rest), ("opacity", m._opacity),
+                     ("scaling", m._scaling), ("rotation", m._rotation)):
+        out[name] = p_.detach().cpu().numpy()
+        st = m.optimizer.state[p_]
+        out[name + "_m"] = st["exp_avg"].cpu().numpy()
+        out[name + "_v"] = st["exp_avg_sq"].cpu().numpy()
+    out["accum"], out["denom"], out["radii"] = m.xyz_gradient_accum.cpu().numpy(), m.denom.cpu().numpy(), m.max_radii2D.cpu().numpy()
+    return out
+
+
+def test_config3_densification_at_size_edits_a_material_share_of_the_rows(hip_lib, capsys, monkeypatch):
+    """Verdict r2 item 8 (gaussian_model.py:583-647 at BASELINE config 3's size).  One densify_and_prune on the 1.5 M
+    room scene in a state where clone, split and prune EACH take >= 5 % of the rows, on the GPU (FusedAdam state, HIP
+    stream compaction):
+      * the selections equal the reference's rules evaluated with plain torch mask arithmetic, the row count is
+        P + clones + splits - pruned exactly, kept rows (parameters AND Adam moments) equal mask indexing bit for bit;
+      * on a 200 000-row subset the same call runs on the CPU path of densify.py -- the one that replays the
+        reference's own GaussianModel bit for bit (tests/test_densify.py) -- from the same state with the same normal
+        draws: identical row counts and selections, tensors equal to float round-off."""
+    real_normal = torch.normal
+    draws = {}
+
+    def normal_from_cpu(mean, std):  # the GPU's generator differs from the CPU's: both sides take the CPU stream
+        key = tuple(std.shape)
+        if key not in draws:
+            g = torch.Generator().manual_seed(1234)
+            draws[key] = real_normal(mean=torch.zeros(std.shape), std=torch.ones(std.shape), generator=g)
+        return draws[key].to(std.device) * std + mean
+
+    monkeypatch.setattr(torch, "normal", normal_from_cpu)
+    dev = torch.device("cuda:0")
+    report = []
+    for P in (1_500_000, 200_000):
+        m = _densify_state(P, dev)
+        before = _snapshot(m)
+        with torch.no_grad():
+            grads = m.xyz_gradient_accum / m.denom
+            grads[grads.isnan()] = 0.0
+            big = m.get_scaling.max(dim=1).values > 0.01 * 6.0
+            hot = grads.squeeze(1) >= 0.0002
+            n_clone = int((hot & ~big).sum())
+            clone_idx = torch.nonzero(hot & ~big).squeeze(1).cpu().numpy()
+            # after the clone pass the set is [P originals | clones]; the split looks at the first P statistics only
+            n_split = int((hot & big).sum())
+            m.densify_and_prune(0.0002, 0.05, 6.0, 20)
+        after = _snapshot(m)
+        n_after = after["xyz"].shape[0]
+        grown = P + n_clone + n_split  # + clones, + 2 children - 1 parent per split
+        pruned = grown - n_after
+        report.append((P, n_clone, n_split, pruned, n_after))
+        assert n_clone >= 0.05 * P and n_split >= 0.05 * P and pruned >= 0.05 * P, report[-1]
+        for k in after:
+            assert after[k].shape[0] == n_after and np.isfinite(after[k]).all(), k
+        # the surviving ORIGINAL rows keep their order: they are the rows of `before` that are neither split nor pruned
+        keep0 = ~(hot & big).cpu().numpy()
+        op_b = 1 / (1 + np.exp(-before["opacity"][:, 0].astype(np.float64)))
+        sc_b = np.exp(before["scaling"].astype(np.float64)).max(axis=1)
+        keep0 &= ~((op_b < 0.05) | (before["radii"] > 20) | (sc_b > 0.6))
+        n0 = int(keep0.sum())
+        # rows whose opacity sits within float round-off of the threshold may fall either way between exp() variants
+        edge = np.abs(op_b - 0.05) < 1e-6
+        if not edge.any():
+            for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
+                np.testing.assert_array_equal(after[k][:n0], before[k][keep0], err_msg=k)
+                np.testing.assert_array_equal(after[k + "_m"][:n0], before[k + "_m"][keep0], err_msg=k)
+                np.testing.assert_array_equal(after[k + "_v"][:n0], before[k + "_v"][keep0], err_msg=k)
+        assert (after["accum"] == 0).all() and (after["denom"] == 0).all()  # statistics restart (gaussian_model.py:579-581)
+        if P == 200_000:
+            cpu = _densify_state(P, torch.device("cpu"))
+            with torch.no_grad():
+                cpu.densify_and_prune(0.0002, 0.05, 6.0, 20)
+            want = _snapshot(cpu)
+            for k in after:
+                assert after[k].shape == want[k].shape, (k, after[k].shape, want[k].shape)
+                scale = np.abs(want[k]).max() + 1e-12
+                assert np.abs(after[k] - want[k]).max() <= 2e-5 * scale, (k, float(np.abs(after[k] - want[k]).max()))
+        del m
+    with capsys.disabled():
+        for P, c, s_, pr, n in report:
+            print(f"\nC3 densify_and_prune at P={P}: cloned {c} ({100 * c / P:.1f} %), split {s_} ({100 * s_ / P:.1f} %), "
+                  f"pruned {pr} ({100 * pr / P:.1f} %) -> {n} rows")
