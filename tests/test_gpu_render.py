@@ -114,7 +114,7 @@ def test_metric_size_properties(hip_lib):
     inp = dict(means3D=scene.means3D, W=W, H=H)
     st = hip_state(dict(R=f1[0], geom=f1[4], binning=f1[5], img=f1[6]), inp)
     ent = st["entries"]
-    tile_of = (ent >> np.uint64(48)).astype(np.int64)
+    tile_of = (ent >> np.uint64(32)).astype(np.int64)
     assert np.all(np.diff(tile_of) >= 0)
     view = np.asarray(cam.world_view_transform, np.float32)
     z = scene.means3D @ view[:3, 2] + view[3, 2]  # p_view.z
