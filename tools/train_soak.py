@@ -20,7 +20,12 @@ from g4splat_amd import synthetic  # noqa: E402
 from g4splat_amd.gaussian_model import GaussianModel  # noqa: E402
 from g4splat_amd.gaussian_renderer import render  # noqa: E402
 from g4splat_amd.losses import geometry_regularizers, photometric_loss  # noqa: E402
-from g4splat_amd.metrics import psnr  # noqa: E402
+
+
+def psnr(img1, img2):  # 2dgs/utils/image_utils.py:19-21
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
 
 
 def main():
