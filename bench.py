@@ -284,17 +284,20 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         n_target = max(500, int(math.ceil(args.sustained_seconds / max(el / args.steps, 1e-6))))
+        first = []
         marks = []  # host time every 50 steps: the reference-shaped forward waits for its read-back, so the host runs at
         for i in range(n_target):   # most one step ahead of the GPU and these times follow the GPU's progress
             if i % 50 == 0:
                 marks.append(time.perf_counter())
+            if i < 10:
+                first.append(time.perf_counter())
             step(i % args.steps)
             units_s += Vs[(rank + (i % args.steps) * world) % len(dcams)]
             n_s += 1
-            if rank == 0 and i in (n_target // 2, (3 * n_target) // 4, n_target - 1):
-                mhz = read_sclk_mhz(local_rank)
-                if mhz is not None:
-                    sclk.append(mhz)
+        if rank == 0:  # one sysfs read (it takes tens of ms: not inside the loop), while the last steps are still running
+            mhz = read_sclk_mhz(local_rank)
+            if mhz is not None:
+                sclk.append(mhz)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -310,9 +313,10 @@ def main():
         sustained = {"steps": n_s, "seconds": round(dt_s, 3), "ms_per_step": round(dt_s / n_s * 1e3, 4),
                      "value": units_s / dt_s, "unit": "Gaussians/s",
                      "effective_clock_GHz": (round(sum(sclk) / len(sclk) / 1e3, 3) if sclk else None),
-                     "clock_source": ("sysfs pp_dpm_sclk (the DPM level in force, not a cycle count) sampled at 1/2, 3/4 and "
-                                      "the end of the pass" if sclk else
+                     "clock_source": ("sysfs pp_dpm_sclk (the DPM level in force, not a cycle count) read once as the "
+                                      "last steps of the pass run" if sclk else
                                       "sysfs pp_dpm_sclk not readable on this box"),
+                     "ms_first_steps": [round((b - a) * 1e3, 3) for a, b in zip(first, first[1:])],
                      "ms_per_step_by_50_steps": [round((b - a) / 50 * 1e3, 4) for a, b in zip(marks, marks[1:])],
                      "note": "same step as the headline, issued back to back right behind it (no pause)"}
 
