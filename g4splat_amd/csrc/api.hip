@@ -66,8 +66,8 @@ hipEvent_t readback_event() {
 // written only by g4s_set_option -- the call paths never touch the environment.
 struct Option { const char* name; std::atomic<int> value; };
 Option g_options[] = {{"box_only", {0}}, {"no_fastpath", {0}}, {"bwd_fwd_order", {0}},
-                      {"bwd_hot_threshold", {G4S_OPTION_UNSET}}, {"no_side_zero", {0}}, {"no_pairs", {0}}};
-enum OptionId { OPT_BOX_ONLY, OPT_NO_FASTPATH, OPT_BWD_FWD_ORDER, OPT_BWD_HOT_THRESHOLD, OPT_NO_SIDE_ZERO, OPT_NO_PAIRS };
+                      {"bwd_hot_threshold", {G4S_OPTION_UNSET}}, {"no_side_zero", {0}}};
+enum OptionId { OPT_BOX_ONLY, OPT_NO_FASTPATH, OPT_BWD_FWD_ORDER, OPT_BWD_HOT_THRESHOLD, OPT_NO_SIDE_ZERO };
 inline int opt(OptionId id) { return g_options[id].value.load(std::memory_order_relaxed); }
 
 inline bool trace_on() {
@@ -429,7 +429,6 @@ static int rasterizer_forward_impl(
     ba.qhit = qhit_ptr;
     ba.box_only = opt(OPT_BOX_ONLY) != 0;
     ba.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
-    ba.no_pairs = opt(OPT_NO_PAIRS) != 0;
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");
     return R;
@@ -557,7 +556,6 @@ static int rasterizer_backward_impl(
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
         bb.n_slots = (uint32_t)R;
         bb.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
-        bb.no_pairs = opt(OPT_NO_PAIRS) != 0;
         // One wave per tile is the efficient form when there are enough tiles to fill the GPU (1 024 SIMDs x 3
         // waves); a small frame (<= 768 tiles, e.g. 256 x 256) runs about twice as fast with four waves per tile,
         // and so does any single tile that is much deeper than the rest (measured: tools/deep_tile_bench.py).

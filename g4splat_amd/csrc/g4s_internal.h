@@ -192,7 +192,6 @@ struct BlendFwdArgs {
     uint32_t* tile_depth;  // per tile (0, number of (entry, quadrant) pairs blended): the backward's work, for its ordering
     int box_only;   // tests (option "box_only"): skip quadrants by the bounding box only
     int no_fastpath;  // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
-    int no_pairs;     // tests (option "no_pairs"): visit the list entries one at a time
     float* out_color;
     float* out_others;
 };
@@ -219,7 +218,6 @@ struct BlendBwdArgs {
     // flagged invalid in the status word; memory stays safe).
     uint32_t n_slots;
     int no_fastpath;   // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
-    int no_pairs;      // tests (option "no_pairs"): visit the list entries one at a time
     // deep tiles (more than hot_threshold live list positions) are left to blend_bwd_hot_kernel: the one-wave
     // kernel appends them to hot_list (hot_count pre-cleared), the four-wave kernel runs behind it
     int hot_threshold;  // < 0: all tiles go to the four-wave kernel (frames with too few tiles to fill the GPU one wave each)

@@ -230,7 +230,6 @@ int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
  *   "bwd_fwd_order"      the blend backward walks the tiles in the forward's order
  *   "bwd_hot_threshold"  list depth above which a tile goes to the four-wave backward (G4S_OPTION_UNSET = automatic)
  *   "no_side_zero"       the blend backward does not clear dL_dsh on the side (K8 clears the rows it skips)
- *   "no_pairs"           the blend kernels visit list entries one at a time (no packed-FP32 pair visits)
  * Returns G4S_OK or G4S_ERR_INVALID_ARGUMENT for an unknown name. */
 #define G4S_OPTION_UNSET (-2147483647 - 1)
 int g4s_set_option(const char* name, int value);

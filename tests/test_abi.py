@@ -65,7 +65,7 @@ def test_diagnostic_switches_are_library_state_not_environment(hip_lib):
     translation unit calls getenv outside the one-time G4S_TRACE probe (nothing on a call path depends on the
     caller's environment)."""
     from g4splat_amd import _lib
-    for name in ("box_only", "no_fastpath", "bwd_fwd_order", "no_side_zero", "no_pairs"):
+    for name in ("box_only", "no_fastpath", "bwd_fwd_order", "no_side_zero"):
         assert _lib.get_option(name) == 0
         with _lib.option(name, 1):
             assert _lib.get_option(name) == 1
