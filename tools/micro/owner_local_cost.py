@@ -27,7 +27,8 @@ stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def kernel(idx, n, buf, mode):
-    assert lib.g4s_pack_rows(k, ptrs, wid, ctypes.c_void_p(idx.data_ptr()), int(n), ctypes.c_void_p(buf.data_ptr()), mode, stream) == 0
+    ip = ctypes.c_void_p(idx.data_ptr() if idx is not None else 0)
+    assert lib.g4s_pack_rows(k, ptrs, wid, ip, int(n), ctypes.c_void_p(buf.data_ptr()), mode, stream) == 0
 
 
 def t(fn, n=20):
@@ -52,23 +53,23 @@ c = counts.tolist()
 n_all = sum(c)
 send_idx = idx[c[0]:n_all].contiguous()   # rank 0: everything but its own shard
 n = n_all - c[0]
-buf = torch.empty(n, W, device=dev)
+# (rows travel with their index as a trailing int32 column: modes 10 = pack, 15 = accumulate with indices from the buffer)
+buf = torch.empty(n, W + 1, device=dev)
 per_src = n // (world - 1) if world > 1 else 0
-in_rows = torch.randn(max(1, per_src), W, device=dev)
+in_rows = torch.randn(max(1, per_src), W + 1, device=dev)
 in_idx = torch.randperm(shard, device=dev)[:max(1, per_src)].sort().values
+in_rows[:, W] = in_idx.to(torch.int32).view(torch.float32)
 
 
-def finish_local():
-    out = torch.empty(n, W, device=dev)
+def finish_local():  # persistent buffers: nothing is allocated here
     if n:
-        kernel(send_idx, n, out, 2)
-    torch.empty(n, W, device=dev); torch.empty(n, dtype=torch.int64, device=dev)
+        kernel(send_idx, n, buf, 10)
     for _s in range(world - 1):
-        kernel(in_idx, per_src, in_rows, 7)
+        kernel(None, per_src, in_rows, 15)
 
 
 print(f"world {world}: {n} rows to send, {per_src} rows per source to accumulate")
 print("begin (index list + counts)      %.3f ms" % t(begin))
-print("pack (one launch)                %.3f ms" % t(lambda: kernel(send_idx, n, buf, 2)))
-print("accumulate (world-1 launches)    %.3f ms" % t(lambda: [kernel(in_idx, per_src, in_rows, 7) for _ in range(world - 1)]))
+print("pack (one launch)                %.3f ms" % t(lambda: kernel(send_idx, n, buf, 10)))
+print("accumulate (world-1 launches)    %.3f ms" % t(lambda: [kernel(None, per_src, in_rows, 15) for _ in range(world - 1)]))
 print("finish, local part               %.3f ms" % t(finish_local))
