@@ -5,8 +5,11 @@ set -u
 TAG=${1:-r01}
 WL=${2:-s3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+# raw rocprofv3 output goes to /tmp (tens of MB); only the summaries are copied into gpurun_out/prof_<tag>/ (gpurun merges
+# at most 64 MiB back)
+OUT=/tmp/prof_$TAG
+KEEP=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT $KEEP
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
 # kernel trace + stats of the SAME command the driver runs (default steps / warm-up; the CPU-baseline leg launches no kernels)
@@ -19,4 +22,7 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -- $BENCH > $OUT/pmc_$name.log 2>&1
 done
 python $REPO/tools/summarize_prof.py $OUT $OUT/traffic_$WL.json $WL "${3:-}" > $OUT/summary.txt 2>&1
+cp $OUT/summary.txt $OUT/traffic_$WL.json $OUT/bench_under_rocprof.json $KEEP/ 2>/dev/null
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $KEEP/kernel_stats.csv \; 2>/dev/null
+tail -5 $OUT/stats.log > $KEEP/stats_tail.log 2>/dev/null
 cat $OUT/summary.txt
