@@ -247,8 +247,8 @@ static int rasterizer_forward_impl(
         return fail(G4S_ERR_INVALID_ARGUMENT, "NULL required pointer");
     const int tiles_x = (width + TILE - 1) / TILE, tiles_y = (height + TILE - 1) / TILE;
     // (tile coordinates travel in 16 bits each -- the binned rect of a Gaussian -- and the tile id in 32)
-    if (tiles_x > 65535 || tiles_y > 65535 || (long long)tiles_x * tiles_y > 0x7FFFFFFFll)
-        return fail(G4S_ERR_INVALID_ARGUMENT, "image too large: %d x %d tiles (at most 65535 per axis)", tiles_x, tiles_y);
+    if (tiles_x > 65535 || tiles_y > 32767 || (long long)tiles_x * tiles_y > 0x7FFFFFFFll)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "image too large: %d x %d tiles (at most 65535 across, 32767 down)", tiles_x, tiles_y);
     const int tiles = tiles_x * tiles_y;
     const size_t N = (size_t)width * height;
 
@@ -552,7 +552,6 @@ static int rasterizer_backward_impl(
         bb.final_T = (const float*)(img + IL.final_T);
         bb.n_contrib = (const uint32_t*)(img + IL.n_contrib);
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
-        bb.tight_rect = (const uint2*)(geom + GL.tight_rect);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
         bb.n_slots = (uint32_t)R;
         bb.no_fastpath = opt(OPT_NO_FASTPATH) != 0;

@@ -40,7 +40,7 @@ __device__ __forceinline__ bool quad_misses_region(const float4 q0, const float4
     // low-pass disk
     const float ddx = fmaxf(fmaxf(qx - q0.x, q0.x - x1), 0.0f), ddy = fmaxf(fmaxf(qy - q0.y, q0.y - y1), 0.0f);
     if (ddx * ddx + ddy * ddy <= q7.z) return false;
-    if (q7.w == 0.0f) return false;  // no ellipse: the bounding box decided
+    if (q7.x == 0.0f) return false;  // no ellipse (1 / a^2 = 0): the bounding box decided
     const float ux = q6.z, uy = q6.w, ia = q7.x, ib = q7.y;
     const float ax0 = qx - q6.x, ax1 = x1 - q6.x, ay0 = qy - q6.y, ay1 = y1 - q6.y;  // rectangle relative to e
     if (ax0 <= 0.0f && ax1 >= 0.0f && ay0 <= 0.0f && ay1 >= 0.0f) return false;      // centre inside
@@ -366,7 +366,9 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
             nolp_l = !a.no_fastpath && (__float_as_uint(q0.w) & REC_NO_LOWPASS) != 0;
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
-            s_slot[lane] = __float_as_uint(q0.z) + instance_number(a.tight_rect[entry_idx(e)], (uint32_t)tile_x, (uint32_t)tile_y);
+            // (the rect's origin word sits in q7.w, in the 64-byte line q4 was just read from)
+            s_slot[lane] = __float_as_uint(q0.z) + instance_number(__float_as_uint(q0.w), __float_as_uint(reinterpret_cast<const float*>(r)[31]),
+                                                                  (uint32_t)tile_x, (uint32_t)tile_y);
         }
         __syncthreads();
 
@@ -605,7 +607,8 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     if (!a.no_fastpath && (__float_as_uint(rq[0].w) & REC_NO_LOWPASS)) qmask |= 16u;
 #pragma unroll
                     for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
-                    s_slot[lane] = __float_as_uint(rq[0].z) + instance_number(a.tight_rect[entry_idx(e)], (uint32_t)tile_x, (uint32_t)tile_y);
+                    s_slot[lane] = __float_as_uint(rq[0].z) + instance_number(__float_as_uint(rq[0].w), __float_as_uint(reinterpret_cast<const float*>(r)[31]),
+                                                                              (uint32_t)tile_x, (uint32_t)tile_y);
                 }
                 s_q[lane] = qmask;
             }

@@ -15,14 +15,16 @@ constexpr int BLEND_QUADS = 5;     // q0..q4: what the per-pixel arithmetic need
 constexpr int GRAD_FLOATS = 18;    // gradient terms per instance (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
 constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 16-byte aligned; last two unused)
 // Splat record (written by the forward preprocess, read by emit / blend / backward):
-//   q0 = (centre.x, centre.y, bits(inst_off), bits(tight tile count | REC_NO_LOWPASS))
+//   q0 = (centre.x, centre.y, bits(inst_off), bits(binned rect width | height << 16 | REC_NO_LOWPASS))
 //   q1 = (normal.xyz (view space, flipped towards the camera), opacity)
 //   q2 = (Tu.x, Tu.y, Tu.z, Tv.x)   q3 = (Tv.y, Tv.z, Tw.x, Tw.y)   q4 = (Tw.z, r, g, b)
 //   q5 = conservative pixel bounding box (x0, y0, x1, y1) of the region where this splat can pass
 //        the 1/255 alpha test (empty: x0 > x1)
-//   q6 = (ex, ey, ux, uy), q7 = (1/a^2, 1/b^2, r2, valid): the same region exactly -- the union of the ellipse
-//        (centre e, unit major axis u, semi-axes a >= b) that the alpha-cutoff disk of the splat projects to and of
-//        the low-pass disk |pixel - centre|^2 <= r2 -- slightly enlarged; valid = 0: no ellipse, use the box
+//   q6 = (ex, ey, ux, uy), q7 = (1/a^2, 1/b^2, r2, bits(binned rect x0 | y0 << 16)): the same region exactly -- the
+//        union of the ellipse (centre e, unit major axis u, semi-axes a >= b) that the alpha-cutoff disk of the splat
+//        projects to and of the low-pass disk |pixel - centre|^2 <= r2 -- slightly enlarged; 1/a^2 = 0: no ellipse, use
+//        the box.  The binned rect lives in q0.w / q7.w: q7 shares its 64-byte line with q4, which the blend backward
+//        reads anyway, so an entry's instance number (gradient-record slot - inst_off) costs it no extra memory traffic.
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 // Keys per thread of the radix passes (a workgroup of 256 threads owns 256 * ITEMS consecutive keys).
 #ifndef G4S_SORT_ITEMS_U32
@@ -42,9 +44,14 @@ inline size_t sort_blocks(size_t n, int items) { return (n + (size_t)256 * items
 constexpr int ENTRY_TILE_SHIFT = 32;
 __host__ __device__ inline uint32_t entry_idx(uint64_t e) { return (uint32_t)e; }
 __host__ __device__ inline uint32_t entry_tile(uint64_t e) { return (uint32_t)(e >> ENTRY_TILE_SHIFT); }
-// tight_rect = (x0 | y0 << 16, width in tiles) of the rect a Gaussian is binned into (row-major instance numbering)
-__host__ __device__ inline uint32_t instance_number(uint2 tight_rect, uint32_t tile_x, uint32_t tile_y) {
-    return (tile_y - (tight_rect.x >> 16)) * tight_rect.y + (tile_x - (tight_rect.x & 0xFFFFu));
+// The rect of tiles a Gaussian is binned into, as the record keeps it: extent word = width | height << 16 (bit 31 is
+// REC_NO_LOWPASS: at most 65 535 tiles across, 32 767 down), origin word = x0 | y0 << 16; row-major instance numbering.
+__host__ __device__ inline uint32_t rect_extent_word(int w, int h) { return (uint32_t)w | ((uint32_t)h << 16); }
+__host__ __device__ inline uint32_t rect_tiles(uint32_t extent_word) {
+    return (extent_word & 0xFFFFu) * ((extent_word >> 16) & 0x7FFFu);
+}
+__host__ __device__ inline uint32_t instance_number(uint32_t extent_word, uint32_t origin_word, uint32_t tile_x, uint32_t tile_y) {
+    return (tile_y - (origin_word >> 16)) * (extent_word & 0xFFFFu) + (tile_x - (origin_word & 0xFFFFu));
 }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -207,7 +214,6 @@ struct BlendBwdArgs {
     const float* final_T;
     const uint32_t* n_contrib;
     const uint8_t* qhit;
-    const uint2* tight_rect;  // per Gaussian: the binned tile rect (gives an entry's instance number = record slot - inst_off)
     const float* dL_dpix;
     const float* dL_depths;
     float* grad_inst;  // R x GRAD_STRIDE, NOT cleared: a record is valid only where rec_flag says so

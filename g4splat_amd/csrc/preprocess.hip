@@ -108,7 +108,7 @@ __device__ __forceinline__ void alpha_cutoff_box(const float* T, float cx, float
 // semi-axes are enlarged: r -> 1.002 sqrt(r^2 + 0.75^2) (0.2 % + three quarters of a pixel in quadrature; that
 // absorbs the float storage of e and the per-pixel rounding of the blend loops and keeps the minor axis above
 // 0.75 px).  Also the squared radius of the low-pass disk (rho2d = 2 |pixel - centre|^2 <= t).  Evaluated in
-// double, once per visible Gaussian.  out[0..7] = ex, ey, ux, uy, 1/a^2, 1/b^2, r2, valid (1 / 0).
+// double, once per visible Gaussian.  out[0..6] = ex, ey, ux, uy, 1/a^2, 1/b^2, r2; 1/a^2 = 0: no ellipse.
 struct CutoffConic {
     double ex, ey, ux, uy, a2, b2;  // centre, unit major axis, squared semi-axes
 };
@@ -190,7 +190,7 @@ __device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, 
     for (int i = 0; i < 6; i++)
         if (!(fabs(vals[i]) < 1e30)) return;  // NaN / overflow: no ellipse
     for (int i = 0; i < 6; i++) out[i] = (float)vals[i];
-    out[7] = 1.0f;
+    // (no validity flag: 1 / a^2 = out[4] > 0 says there is an ellipse; out[7] belongs to the caller)
 }
 
 // REC_NO_LOWPASS: true if (a) the interpolated depth cannot fall below the near plane where the splat passes the alpha
@@ -381,7 +381,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         if (touched != 0) a.tight_rect[idx] = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)(tx1 - tx0));
                         rec[0] = cx;
                         rec[1] = cy;
-                        rec[3] = __uint_as_float(touched | (lowpass_never_matters(T, cx, cy, opa) ? REC_NO_LOWPASS : 0u));
+                        // q0.w = binned rect (width | height << 16) | REC_NO_LOWPASS; q7.w = its origin (x0 | y0 << 16)
+                        rec[3] = __uint_as_float(rect_extent_word(tx1 - tx0, ty1 - ty0) |
+                                                 (lowpass_never_matters(T, cx, cy, opa) ? REC_NO_LOWPASS : 0u));
                         rec[4] = normal.x;
                         rec[5] = normal.y;
                         rec[6] = normal.z;
@@ -393,7 +395,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         rec[21] = box.y;
                         rec[22] = box.z;
                         rec[23] = box.w;
-                        if (touched != 0) alpha_cutoff_ellipse(T, opa, rec + 24);
+                        if (touched != 0) alpha_cutoff_ellipse(T, opa, rec + 24);  // rec[28] (1 / a^2) stays 0 when there is no ellipse
+                        rec[31] = __uint_as_float((uint32_t)tx0 | ((uint32_t)ty0 << 16));
                     }
                 }
             }
@@ -645,7 +648,7 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
     if (visible) {
         const float4 q0 = rq[0];
         my_off = __float_as_uint(q0.z);
-        my_cnt = __float_as_uint(q0.w) & ~REC_NO_LOWPASS;
+        my_cnt = rect_tiles(__float_as_uint(q0.w));
         // (only a frame that overflowed its presized capacity has slots beyond the buffers: never read them)
         if (my_off >= a.n_slots) my_cnt = 0;
         else if (my_cnt > a.n_slots - my_off) my_cnt = a.n_slots - my_off;

@@ -70,7 +70,7 @@ const char* g4s_version(void);
  * reference's) or a negative G4S_ERR_*.  Contains ONE host synchronisation (reading
  * num_rendered to size the binning chunk), exactly like the reference
  * (rasterizer_impl.cu:281-282).
- * Limit: at most 65535 tiles (1 048 560 pixels) per axis.
+ * Limit: at most 65535 tiles (1 048 560 pixels) across and 32767 tiles (524 272 pixels) down.
  */
 int g4s_rasterizer_forward(
     g4s_resize_fn geometry_buffer, void* geometry_ctx,
