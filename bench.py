@@ -87,6 +87,9 @@ def main():
                     help="leave Python's cyclic garbage collector as it is (default: gc.collect() + gc.freeze() after the "
                          "warm-up, so that a full collection over the interpreter's ~10^6 long-lived objects cannot land "
                          "inside a timed pass; host-side hygiene, the GPU work is unchanged)")
+    ap.add_argument("--views-in-flight", type=int, default=3,
+                    help="N = 1 only, reported next to the headline (never as `value`): throughput with up to this many "
+                         "INDEPENDENT views in flight on separate HIP streams (multi-view batches; 0 / 1 = skip)")
     ap.add_argument("--presized", action="store_true",
                     help="use g4s_rasterizer_forward_presized (no host read-back; extension) instead of the "
                          "reference-shaped forward -- for the step-time comparison in DESIGN.md, not the default")
@@ -453,6 +456,20 @@ def main():
                                            "instances -- / this run's step time (this build moves fewer bytes: a 2-pass tile "
                                            "partition of depth-ordered instances)"}}
 
+    vif = None
+    if world == 1 and args.views_in_flight > 1 and len(dcams) > 1:
+        per_k, ref_digest = {}, None
+        for nv in range(1, args.views_in_flight + 1):
+            ms, gps, digest = run_views_in_flight(lib, _C, device, dev, dcams, P, W, H, D, Vs, Rs, nv,
+                                                  max(100, 5 * args.steps), dL_dcolor, dL_dothers)
+            ref_digest = ref_digest or digest
+            assert digest == ref_digest, "a view's results changed with its neighbours"
+            per_k[str(nv)] = {"ms_per_view": round(ms, 4), "value": gps}
+        vif = {"unit": "Gaussians/s", "by_views_in_flight": per_k, "forward": "presized (no host read-back)",
+                 "note": "NOT the headline: K independent views of one multi-view batch on K HIP streams (each with its own "
+                         "state, workspace and outputs; one host thread); every view's outputs and gradients are "
+                         "bit-identical whatever runs beside it.  The reference's loop is one view per optimiser step."}
+
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
         cpu_baseline = run_cpu_baseline(scene, cams[0], P, W, H, D)
@@ -487,11 +504,62 @@ def main():
                            "clock_state": ("settled (behind the sustained pass)" if sustained else "as found")}
                           if elapsed_events is not None else None),
         "sustained": sustained,
+        "views_in_flight": vif,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def run_views_in_flight(lib, _C, device, dev, dcams, P, W, H, D, Vs, Rs, K, steps, dL_dcolor, dL_dothers):
+    """Throughput with K independent views in flight (tools/views_in_flight.py has the stand-alone form): K HIP streams,
+    each with its own PresizedState (no host read-back), backward workspace and outputs; step i goes to stream i % K.
+    Views of one multi-view batch (gradient accumulation; SURVEY.md 8(e)'s 8 views over fewer than 8 GPUs) are
+    independent, so one view's launch-bound binning and HBM-bound per-Gaussian kernels run beside another view's
+    VALU-bound blend kernels.  Returns (ms per view, Gaussians/s, digest of view 1's results)."""
+    bg = torch.zeros(3, device=device)
+    empty = torch.empty(0, device=device)
+    cap = int(max(Rs.values()) * 1.25) + 4096
+    ws_bytes = lib.g4s_rasterizer_backward_workspace(P, cap)
+    streams = [torch.cuda.Stream(device=device) for _ in range(K)]
+    states, works = [], []
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            states.append(_C.PresizedState(P, W, H, cap, device))
+            works.append(torch.empty(ws_bytes, dtype=torch.uint8, device=device))
+    torch.cuda.synchronize()
+
+    def one(i, keep=False):
+        k = i % K
+        c = dcams[i % len(dcams)]
+        with torch.cuda.stream(streams[k]):
+            fw = _C.rasterize_gaussians_presized(states[k], bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
+                                                 dev["rotations"], 1.0, empty, c["view"], c["proj"], c["tanfovx"],
+                                                 c["tanfovy"], H, W, dev["sh"], D, c["campos"], False, False)
+            gr = _C.rasterize_gaussians_backward(bg, dev["means3D"], fw[3], empty, dev["scales"], dev["rotations"], 1.0,
+                                                 empty, c["view"], c["proj"], c["tanfovx"], c["tanfovy"], dL_dcolor,
+                                                 dL_dothers, dev["sh"], D, c["campos"], fw[4], fw[0], fw[5], fw[6], False,
+                                                 out={"workspace": works[k]})
+        return (fw, gr) if keep else None
+
+    for i in range(2 * K + 2):
+        one(i)
+    torch.cuda.synchronize()
+    fw, gr = one(1 % len(dcams), keep=True)  # the same view whatever K is: its results must not depend on its neighbours
+    one(2)
+    torch.cuda.synchronize()
+    digest = [fw[1].double().sum().item(), fw[2].double().sum().item()] + [x.double().sum().item() for x in gr if torch.is_tensor(x)]
+    assert all(int(st.status[3].item()) == 0 for st in states), "presized capacity overflow"
+    del fw, gr
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    units = sum(Vs[i % len(dcams)] for i in range(steps))
+    return dt / steps * 1e3, units / dt, digest
 
 
 def read_sclk_mhz(device_index=0):
