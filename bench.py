@@ -207,6 +207,28 @@ def main():
                 exchange_events.append(ev)
         return R, radii
 
+    # Host hygiene: a generation-2 collection of CPython's cyclic GC walks every long-lived object of the process (torch,
+    # numpy, the scene: ~50 ms here) and lands wherever the allocation counters trip -- measured as ONE 53-ms stall in a
+    # 500-step pass, i.e. the whole difference between the 20-step headline and the "sustained" rate of round 2.  Long-
+    # running loops freeze the startup heap; so does this one -- BEFORE the warm-up steps, so that no host pause sits between
+    # the warm-up and the timed pass (a GPU left idle for the 0.1 s a collection takes starts the timed steps from a lower
+    # power state).  The collections that still happen are timed and reported.
+    import gc
+    gc_ms = [0.0, 0]
+    gc_t0 = [0.0]
+
+    def _gc_cb(phase, info):
+        if phase == "start":
+            gc_t0[0] = time.perf_counter()
+        else:
+            gc_ms[0] += (time.perf_counter() - gc_t0[0]) * 1e3
+            gc_ms[1] += 1
+
+    gc.callbacks.append(_gc_cb)
+    if not args.no_gc_freeze:
+        gc.collect()
+        gc.freeze()
+
     # warm-up (also measures V and R per view outside the timed region)
     Vs, Rs = {}, {}
     if dist is not None and exchange == "owner":
@@ -240,25 +262,6 @@ def main():
         assert pstate.status.tolist()[3] == 0
     timing = not args.no_kernel_timing
     lib.g4s_profile_reset()
-    # Host hygiene: a generation-2 collection of CPython's cyclic GC walks every long-lived object of the process (torch,
-    # numpy, the scene: ~50 ms here) and lands wherever the allocation counters trip -- measured as ONE 53-ms stall in a
-    # 500-step pass, i.e. the whole difference between the 20-step headline and the "sustained" rate of round 2.  Long-
-    # running loops freeze the startup heap; so does this one.  The collections that still happen are timed and reported.
-    import gc
-    gc_ms = [0.0, 0]
-    gc_t0 = [0.0]
-
-    def _gc_cb(phase, info):
-        if phase == "start":
-            gc_t0[0] = time.perf_counter()
-        else:
-            gc_ms[0] += (time.perf_counter() - gc_t0[0]) * 1e3
-            gc_ms[1] += 1
-
-    gc.callbacks.append(_gc_cb)
-    if not args.no_gc_freeze:
-        gc.collect()
-        gc.freeze()
 
     def timed_steps(with_events):
         """EXACTLY args.steps steps between barrier + synchronize on both sides.  with_events: the library brackets
