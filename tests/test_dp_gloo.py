@@ -303,6 +303,32 @@ def _zero1_worker(rank, world, port, q):
         lo, hi = red_b.bounds()
         shard_only = all(t.shape[0] == hi - lo for t in opt.exp_avg)
         no_realloc = (red_a.allocations, red_b.allocations)
+        # a densification changes P and with it the shard boundaries: the moments are gathered, edited like the
+        # (replicated) parameters -- here: every third row pruned -- and re-sharded; one more step on each side
+        keep = torch.ones(P, dtype=torch.bool)
+        keep[::3] = False
+        P2 = int(keep.sum())
+        params_a = [p_[keep].contiguous() for p_ in params_a]
+        params_b = [p_[keep].contiguous() for p_ in params_b]
+        m_full = [t_[keep].contiguous() for t_ in m_full]
+        v_full = [t_[keep].contiguous() for t_ in v_full]
+        grads_a = [torch.zeros(P2, w) for w in widths]
+        grads_b = [torch.zeros(P2, w) for w in widths]
+        side_a, side_b = torch.zeros(P2, 2), torch.zeros(P2, 2)
+        red_a, red_b = OwnerReduce(grads_a + [side_a]), OwnerReduce(grads_b + [side_b])
+        opt.load_full_state(params_b, grads_b, red_b, [t_[keep] for t_ in ea], [t_[keep] for t_ in es])
+        g = torch.Generator().manual_seed(777 + rank)
+        vis = torch.rand(P2, generator=g) < 0.5
+        for ga, gb, w in zip(grads_a, grads_b, widths):
+            vals = torch.randn(P2, w, generator=g)
+            ga[vis] = vals[vis]; gb[vis] = vals[vis]
+        red_a.begin(vis); red_a.finish()
+        for p_, g_, m_, v_, lr in zip(params_a, grads_a, m_full, v_full, lrs):
+            adam_update_(p_, g_, m_, v_, lr, 5, eps=1e-15)
+        red_b.begin(vis); red_b.finish(gather=False); opt.step(extra=[side_b])
+        same_params = same_params and all(torch.equal(a, b) for a, b in zip(params_a, params_b))
+        lo2, hi2 = red_b.bounds()
+        shard_only = shard_only and all(t.shape[0] == hi2 - lo2 for t in opt.exp_avg)
         digest = torch.cat([p.reshape(-1) for p in params_b]).double().sum().item()
         out.append((P, same_params, same_side, same_state, shard_only, allocs, no_realloc, digest))
     q.put((rank, out))
@@ -316,7 +342,9 @@ def test_owner_applied_adam_equals_the_replicated_optimiser(world):
     Against the replicated optimiser on gathered gradients, over four steps at world sizes 2 / 4 / 8, equal and ragged
     shards: parameters, statistics and (gathered) optimiser state are bit-identical, the radii MAX that rides in
     begin()'s collective equals a plain MAX all-reduce, every replica ends with the same bits, optimiser state exists
-    for the rank's shard only, and the exchange allocates nothing after its warm-up (persistent buffers)."""
+    for the rank's shard only, the exchange allocates nothing after its warm-up (persistent buffers), and after a
+    densification-like row edit (moments gathered, every third row pruned, state re-sharded for the new P) the next step
+    still matches bit for bit."""
     _setup_paths()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
