@@ -181,3 +181,34 @@ def test_owner_reduce_and_sharded_adam_on_the_rccl_backend():
     assert same and radii_ok and stepped and finite
     assert allocs <= 2, allocs
     assert isinstance(coalesced, bool)
+
+
+def test_views_in_flight_on_separate_streams_are_bit_identical(hip_lib):
+    """Multi-view batches (bench.py's `views_in_flight`): K independent views on K HIP streams,
+    each with its own PresizedState, workspace and outputs, issued round-robin by one host thread.  A view's outputs and
+    gradients must not depend on what runs beside it: the digest of view 1 is the same for K = 1, 2 and 3."""
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from g4splat_amd import _lib
+    from g4splat_amd.diff_surfel_rasterization import _C
+    device = torch.device("cuda", 0)
+    scene, cams, dev, dcams, (P, W, H, D) = bench.build_scene("s2", device)
+    bg = torch.zeros(3, device=device)
+    empty = torch.empty(0, device=device)
+    g = torch.Generator(device=device).manual_seed(1)
+    gc_ = torch.randn((3, H, W), device=device, generator=g)
+    go_ = torch.randn((7, H, W), device=device, generator=g)
+    Rs, Vs = {}, {}
+    for i, c in enumerate(dcams):
+        fw = _C.rasterize_gaussians(bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0, empty,
+                                    c["view"], c["proj"], c["tanfovx"], c["tanfovy"], H, W, dev["sh"], D, c["campos"], False, False)
+        Rs[i], Vs[i] = int(fw[0]), int((fw[3] > 0).sum())
+    ref, rates = None, []
+    for K in (1, 2, 3):
+        ms, gps, digest = bench.run_views_in_flight(_lib.load(), _C, device, dev, dcams, P, W, H, D, Vs, Rs, K, 24, gc_, go_)
+        ref = ref or digest
+        assert digest == ref, (K, digest, ref)
+        rates.append(gps)
+    assert all(r > 0 for r in rates)
