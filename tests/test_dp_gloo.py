@@ -230,11 +230,11 @@ def _owner_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_owner_reduce_equals_dense_all_reduce(world):
     """OwnerReduce (all_to_all of visible rows to index-shard owners, all_gather of the reduced shards) against the dense
-    SUM all-reduce: bit-identical on exactly representable values at 2 and 4 ranks (ragged last shard, empty and full
-    visibility included), bit-identical on arbitrary values at 2 ranks, equal to rounding at 4, and bit-reproducible."""
+    SUM all-reduce: bit-identical on exactly representable values at 2, 4 and 8 ranks (ragged last shard, empty and full
+    visibility included), bit-identical on arbitrary values at 2 ranks, equal to rounding at 4 and 8, and bit-reproducible."""
     _setup_paths()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
