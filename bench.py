@@ -521,29 +521,22 @@ def run_views_in_flight(lib, _C, device, dev, dcams, P, W, H, D, Vs, Rs, K, step
     Views of one multi-view batch (gradient accumulation; SURVEY.md 8(e)'s 8 views over fewer than 8 GPUs) are
     independent, so one view's launch-bound binning and HBM-bound per-Gaussian kernels run beside another view's
     VALU-bound blend kernels.  Returns (ms per view, Gaussians/s, digest of view 1's results)."""
+    from g4splat_amd.pipeline import ViewPipeline
     bg = torch.zeros(3, device=device)
     empty = torch.empty(0, device=device)
     cap = int(max(Rs.values()) * 1.25) + 4096
-    ws_bytes = lib.g4s_rasterizer_backward_workspace(P, cap)
-    streams = [torch.cuda.Stream(device=device) for _ in range(K)]
-    states, works = [], []
-    for s_ in streams:
-        with torch.cuda.stream(s_):
-            states.append(_C.PresizedState(P, W, H, cap, device))
-            works.append(torch.empty(ws_bytes, dtype=torch.uint8, device=device))
-    torch.cuda.synchronize()
+    pipe = ViewPipeline(P, W, H, cap, device, k=K)
 
     def one(i, keep=False):
-        k = i % K
         c = dcams[i % len(dcams)]
-        with torch.cuda.stream(streams[k]):
-            fw = _C.rasterize_gaussians_presized(states[k], bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
+        with pipe.slot(i) as (state, work):
+            fw = _C.rasterize_gaussians_presized(state, bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
                                                  dev["rotations"], 1.0, empty, c["view"], c["proj"], c["tanfovx"],
                                                  c["tanfovy"], H, W, dev["sh"], D, c["campos"], False, False)
             gr = _C.rasterize_gaussians_backward(bg, dev["means3D"], fw[3], empty, dev["scales"], dev["rotations"], 1.0,
                                                  empty, c["view"], c["proj"], c["tanfovx"], c["tanfovy"], dL_dcolor,
                                                  dL_dothers, dev["sh"], D, c["campos"], fw[4], fw[0], fw[5], fw[6], False,
-                                                 out={"workspace": works[k]})
+                                                 out={"workspace": work})
         return (fw, gr) if keep else None
 
     for i in range(2 * K + 2):
@@ -553,7 +546,7 @@ def run_views_in_flight(lib, _C, device, dev, dcams, P, W, H, D, Vs, Rs, K, step
     one(2)
     torch.cuda.synchronize()
     digest = [fw[1].double().sum().item(), fw[2].double().sum().item()] + [x.double().sum().item() for x in gr if torch.is_tensor(x)]
-    assert all(int(st.status[3].item()) == 0 for st in states), "presized capacity overflow"
+    assert not pipe.overflowed(), "presized capacity overflow"
     del fw, gr
     torch.cuda.synchronize()
     t0 = time.perf_counter()
