@@ -11,6 +11,8 @@ The autograd node calls `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backw
 reference's argument tuples (:60-80, :109-130) and returns gradients in input order
 (:144-154).  `_C` here is the ctypes front-end of the HIP library (./_C.py), not a pybind module.
 """
+import contextlib
+import threading
 from typing import NamedTuple
 
 import torch
@@ -18,7 +20,37 @@ from torch import nn
 
 from . import _C
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "presized"]
+
+_slot = threading.local()
+
+
+@contextlib.contextmanager
+def presized(state, workspace=None):
+    """Extension over the reference (g4splat_amd.pipeline.ViewPipeline.slot enters it): inside this context the autograd
+    node renders through `_C.rasterize_gaussians_presized` with `state` (a `_C.PresizedState`: the forward's scratch lives
+    in it and the host never waits for `num_rendered`) and its backward uses `workspace` (uint8 tensor of at least
+    g4s_rasterizer_backward_workspace(P, state.capacity) bytes) instead of allocating one.  The node's forward state IS
+    `state`: run this view's backward before the next forward that uses the same state, and check `state.status[3]`
+    (instance capacity exceeded: that frame is invalid) when convenient."""
+    prev = getattr(_slot, "value", None)
+    _slot.value = (state, workspace)
+    try:
+        yield
+    finally:
+        _slot.value = prev
+
+
+def _forward(fwd_args):
+    """(outputs of _C.rasterize_gaussians, backward workspace or None) through the presized entry when a slot is active."""
+    slot = getattr(_slot, "value", None)
+    if slot is None:
+        return _C.rasterize_gaussians(*fwd_args), None
+    return _C.rasterize_gaussians_presized(slot[0], *fwd_args), slot[1]
+
+
+def _backward(bwd_args, workspace):
+    return _C.rasterize_gaussians_backward(*bwd_args, out=None if workspace is None else {"workspace": workspace})
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -77,8 +109,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         fwd_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                     rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
-            _C.rasterize_gaussians, fwd_args, rs.debug, "snapshot_fw.dump",
+        (num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer), ctx.workspace = _call_guarded(
+            _forward, (fwd_args,), rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -98,7 +130,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_guarded(
-            _C.rasterize_gaussians_backward, bwd_args, rs.debug, "snapshot_bw.dump",
+            _backward, (bwd_args, ctx.workspace), rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # one gradient per forward input, in input order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
@@ -117,8 +149,8 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
         fwd_args = (rs.bg, means3D, empty, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
                     (sh_dc, sh_rest), rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_guarded(
-            _C.rasterize_gaussians, fwd_args, rs.debug, "snapshot_fw.dump",
+        (num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer), ctx.workspace = _call_guarded(
+            _forward, (fwd_args,), rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -139,7 +171,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
                     rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, _grad_colors, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_guarded(
-            _C.rasterize_gaussians_backward, bwd_args, rs.debug, "snapshot_bw.dump",
+            _backward, (bwd_args, ctx.workspace), rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         return (grad_means3D, grad_means2D, grad_sh[0], grad_sh[1], grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)

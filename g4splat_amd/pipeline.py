@@ -14,6 +14,27 @@ view at K = 3, S2 0.59 -> 0.37, S5 2.75 -> 1.92; every view's results are bit-id
             grads[i] = _C.rasterize_gaussians_backward(..., fw[4], fw[0], fw[5], fw[6], False, out={"workspace": workspace, ...})
     pipe.join()                                           # the caller's stream waits for all of them
 
+Through the autograd node (the reference's `render()` path) the slot is picked up by itself:
+
+    pipe.order_accumulation(gaussians.parameters())      # once: see below
+    for i, view in enumerate(batch):
+        with pipe.slot(i):                                # diff_surfel_rasterization.presized(state, workspace) is active
+            out = render(view, gaussians, pipe_cfg, bg)   # gaussian_renderer.render, unchanged
+            loss_of(out, view).backward()                 # runs on the slot's stream (autograd replays forward streams)
+            pipe.after_previous_view()                    # before touching anything the views share:
+            gaussians.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
+    pipe.join(); optimizer.step()
+
+What the views SHARE must be ordered by hand, because two backward() calls on two streams are two unrelated graphs to
+autograd: each accumulates into the leaves' .grad on its own stream, and `grad += g` from two streams at once loses
+updates (seen as run-to-run differences of the parameters, not as an error).  `order_accumulation(params)` registers a hook
+on every leaf that makes the accumulating stream wait for the previous view's slot to finish (an event recorded when a slot
+exits; by then that view's backward has been issued), so the accumulations happen one after the other in program order and
+the sums are bit-identical to the sequential loop's.  `after_previous_view()` is the same wait for user code (densification
+statistics, running means).  The waits sit at the very end of a view's backward: nothing of the overlap is lost.
+(Keep the leaves' .grad buffers persistent -- zero_grad(set_to_none=False) -- so that no gradient tensor moves from one
+stream's allocator pool to another stream's reader; a view's backward must be issued before its slot is used again.)
+
 Every slot owns a PresizedState (g4s_rasterizer_forward_presized: no host read-back, so the one host thread never blocks),
 a backward workspace and -- through torch's per-stream allocator pools -- its output tensors.  The backward OVERWRITES its
 outputs: gradients of different views must land in different buffers and be summed afterwards."""
@@ -35,6 +56,9 @@ class ViewPipeline:
         ws_bytes = lib.g4s_rasterizer_backward_workspace(int(P), int(instance_capacity))
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.k)]
         self.states, self.workspaces = [], []
+        self._done = [torch.cuda.Event() for _ in range(self.k)]  # recorded when a slot exits
+        self._last_done = None
+        self._hooks = []
         for s in self.streams:
             with torch.cuda.stream(s):
                 self.states.append(_C.PresizedState(P, width, height, instance_capacity, self.device))
@@ -48,8 +72,35 @@ class ViewPipeline:
         j = i % self.k
         s = self.streams[j]
         s.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(s):
-            yield self.states[j], self.workspaces[j]
+        from .diff_surfel_rasterization import presized
+        with torch.cuda.stream(s), presized(self.states[j], self.workspaces[j]):
+            try:
+                yield self.states[j], self.workspaces[j]
+            finally:
+                self._done[j].record(s)
+                self._last_done = self._done[j]
+
+    def after_previous_view(self):
+        """The current stream waits until everything issued inside the most recently exited slot has finished.  Call it
+        inside a slot before updating state that the views share."""
+        ev = self._last_done
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def order_accumulation(self, params):
+        """Registers a gradient hook on every leaf in `params`: its accumulation into .grad waits for the previous view
+        (see the module docstring).  Returns the hook handles (also kept in the pipeline; `release_hooks()` removes them)."""
+        def hook(grad):
+            self.after_previous_view()
+            return grad
+        handles = [p.register_hook(hook) for p in params]
+        self._hooks.extend(handles)
+        return handles
+
+    def release_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def join(self):
         """The caller's current stream waits for every slot's stream."""

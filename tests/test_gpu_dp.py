@@ -212,3 +212,89 @@ def test_views_in_flight_on_separate_streams_are_bit_identical(hip_lib):
         assert digest == ref, (K, digest, ref)
         rates.append(gps)
     assert all(r > 0 for r in rates)
+
+
+def test_multi_view_batch_through_render_and_autograd_on_two_streams():
+    """A multi-view batch (8 views over fewer than 8 GPUs, accumulated locally) through the reference's
+    own call sequence -- gaussian_renderer.render(), a loss, loss.backward() -- with each view inside a ViewPipeline slot:
+    the autograd node picks the slot's PresizedState up by itself (diff_surfel_rasterization.presized), forward and
+    backward of a view run on the slot's stream, the parameters' .grad accumulate across views -- in program order, which
+    ViewPipeline.order_accumulation enforces (two backward() calls on two streams are unrelated graphs to autograd and
+    would add into .grad concurrently).  Must equal the same batch rendered view after view on the default stream, bit for
+    bit, images and summed gradients, five times in a row."""
+    import contextlib
+    import math
+    from types import SimpleNamespace
+    import numpy as np
+    from g4splat_amd import _lib, synthetic
+    from g4splat_amd.gaussian_model import GaussianModel
+    from g4splat_amd.gaussian_renderer import render
+    from g4splat_amd.pipeline import ViewPipeline
+    dev = torch.device("cuda", 0)
+    P, W, H = 120_000, 640, 400
+    scene = synthetic.scene_room(P, seed=2)
+    cams = []
+    for c in synthetic.room_cameras(4, W, H, fovx_deg=90.0):
+        cams.append(SimpleNamespace(image_width=W, image_height=H, FoVx=c.FoVx, FoVy=c.FoVy,
+                                    world_view_transform=torch.tensor(c.world_view_transform, device=dev),
+                                    full_proj_transform=torch.tensor(c.full_proj_transform, device=dev),
+                                    camera_center=torch.tensor(c.camera_center, device=dev), znear=0.01, zfar=100.0))
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    model = GaussianModel(sh_degree=3)
+    model.create_from_parameters(t(scene.means3D), t(scene.scales), t(scene.rotations),
+                                 t(np.clip(scene.shs[:, 0, :] * 0.28209479177387814 + 0.5, 0, 1).astype(np.float32)))
+    model.active_sh_degree = 3
+    params = [model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity]
+    for p in params:
+        p.requires_grad_(True)
+        p.grad = torch.zeros_like(p)
+    cfg = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    wc = [torch.randn((3, H, W), device=dev, generator=g) for _ in cams]
+    wn = [torch.randn((3, H, W), device=dev, generator=g) for _ in cams]
+
+    def view_loss(out, i):
+        return (out["render"] * wc[i]).sum() + (out["rend_normal"] * wn[i]).sum() + 10.0 * out["rend_dist"].mean() \
+            + out["surf_depth"].mean()
+
+    def run(pipe):
+        for p in params:
+            p.grad.zero_()
+        images = []
+        for i, cam in enumerate(cams):
+            ctx = pipe.slot(i) if pipe is not None else contextlib.nullcontext()
+            with ctx:
+                out = render(cam, model, cfg, bg)
+                view_loss(out, i).backward()
+                images.append(out["render"].detach())
+        if pipe is not None:
+            pipe.join()
+        torch.cuda.synchronize()
+        return [im.cpu() for im in images], [p.grad.detach().cpu().clone() for p in params]
+
+    lib = _lib.load()
+    im0, g0 = run(None)
+    # capacity: the largest instance count of the four views, with headroom (the host never sees the counts in a slot)
+    from g4splat_amd.diff_surfel_rasterization import _C
+    R, empty = 0, torch.empty(0, device=dev)
+    for cam in cams:
+        fw = _C.rasterize_gaussians(bg, model.get_xyz.detach(), empty, model.get_opacity.detach(), model.get_scaling.detach(),
+                                    model.get_rotation.detach(), 1.0, empty, cam.world_view_transform, cam.full_proj_transform,
+                                    math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), H, W, model.get_features.detach(), 3,
+                                    cam.camera_center, False, False)
+        R = max(R, int(fw[0]))
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    pipe = ViewPipeline(P, W, H, int(R * 1.25), dev, k=2)
+    pipe.order_accumulation(params)
+    for rep in range(5):
+        im1, g1 = run(pipe)
+        assert not pipe.overflowed()
+        for a, b in zip(im0, im1):
+            assert torch.equal(a, b)
+        for name, a, b in zip(("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"), g0, g1):
+            assert a.abs().max() > 0, name
+            assert torch.equal(a, b), (rep, name, (a - b).abs().max().item() / (a.abs().max().item() + 1e-30))
+    pipe.release_hooks()
+    # and the slot really was used: the second run's forward states are the pipeline's
+    assert lib is not None and all(int(st.status[1].item()) > 0 for st in pipe.states)
