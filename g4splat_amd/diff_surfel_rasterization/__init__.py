@@ -41,7 +41,7 @@ def presized(state, workspace=None):
         _slot.value = prev
 
 
-def _forward(fwd_args):
+def _forward(*fwd_args):
     """(outputs of _C.rasterize_gaussians, backward workspace or None) through the presized entry when a slot is active."""
     slot = getattr(_slot, "value", None)
     if slot is None:
@@ -49,8 +49,10 @@ def _forward(fwd_args):
     return _C.rasterize_gaussians_presized(slot[0], *fwd_args), slot[1]
 
 
-def _backward(bwd_args, workspace):
-    return _C.rasterize_gaussians_backward(*bwd_args, out=None if workspace is None else {"workspace": workspace})
+def _backward(workspace):
+    def call(*bwd_args):
+        return _C.rasterize_gaussians_backward(*bwd_args, out=None if workspace is None else {"workspace": workspace})
+    return call
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -110,7 +112,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                     rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         (num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer), ctx.workspace = _call_guarded(
-            _forward, (fwd_args,), rs.debug, "snapshot_fw.dump",
+            _forward, fwd_args, rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -130,7 +132,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_guarded(
-            _backward, (bwd_args, ctx.workspace), rs.debug, "snapshot_bw.dump",
+            _backward(ctx.workspace), bwd_args, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # one gradient per forward input, in input order; raster_settings gets None
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
@@ -150,7 +152,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width,
                     (sh_dc, sh_rest), rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         (num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer), ctx.workspace = _call_guarded(
-            _forward, (fwd_args,), rs.debug, "snapshot_fw.dump",
+            _forward, fwd_args, rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -171,7 +173,7 @@ class _RasterizeGaussiansSplitSH(torch.autograd.Function):
                     rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, _grad_colors, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_guarded(
-            _backward, (bwd_args, ctx.workspace), rs.debug, "snapshot_bw.dump",
+            _backward(ctx.workspace), bwd_args, rs.debug, "snapshot_bw.dump",
             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         return (grad_means3D, grad_means2D, grad_sh[0], grad_sh[1], grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
