@@ -491,6 +491,10 @@ class ViewParallel:
             vp.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
         stats = vp.all_reduce()                           # ONE sum over xGMI + the small side channel
         optimizer.step(); vp.zero()
+
+    A rank that holds several views of the batch (8 views over 1 / 2 / 4 GPUs) can keep two of them in flight: put the body
+    of the loop in `with pipe.slot(j):` of a pipeline.ViewPipeline (after `pipe.order_accumulation(params)`, with
+    `pipe.after_previous_view()` in front of `record_view`) and `pipe.join()` before `all_reduce()`.
     """
 
     def __init__(self, params: Iterable[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
