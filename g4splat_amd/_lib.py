@@ -56,6 +56,8 @@ SIGNATURES = {
     "g4s_profile_reset": (None, []),
     # include/g4s_optim.h
     "g4s_adam_step": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_p]),
+    "g4s_adam_step_device": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                   c_p]),
     "g4s_densify_stats": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "g4s_activations_forward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "g4s_activations_backward": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

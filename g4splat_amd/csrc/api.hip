@@ -752,6 +752,33 @@ extern "C" int g4s_adam_step(int nseg, float* const* params, const float* const*
     return G4S_OK;
 }
 
+extern "C" void g4s_adam_device_launch_internal(int nseg, float* const* params, const float* const* grads,
+                                                float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
+                                                const float* lr_dev, float* const* step_dev, float* coef_dev, double beta1,
+                                                double beta2, double eps, hipStream_t s);
+
+extern "C" int g4s_adam_step_device(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
+                                    float* const* exp_avg_sq, const long long* numel, const float* lr_dev,
+                                    float* const* step_dev, float* coef_dev, double beta1, double beta2, double eps,
+                                    void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (nseg < 1 || nseg > 8) return fail(G4S_ERR_INVALID_ARGUMENT, "1..8 segments");
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr_dev || !step_dev || !coef_dev)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL array");
+    for (int i = 0; i < nseg; i++) {
+        if (numel[i] < 0 || !step_dev[i]) return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: numel < 0 or NULL step", i);
+        if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))
+            return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: NULL pointer", i);
+    }
+    { ProfScope ps(PF_ADAM, stream);
+      g4s_adam_device_launch_internal(nseg, params, grads, exp_avg, exp_avg_sq, numel, lr_dev, step_dev, coef_dev, beta1, beta2,
+                                      eps, stream); }
+    CHECK_LAUNCH("adam_step_device");
+    return G4S_OK;
+}
+
 // ---- stream compaction of Gaussian rows (include/g4s_optim.h) ------------------------------------
 extern "C" int g4s_compact_scan_launch_internal(int P, const uint8_t* keep, int* out_count, char* workspace, hipStream_t s);
 extern "C" int g4s_compact_gather_launch_internal(int P, const uint8_t* keep, const char* workspace, int nseg,

@@ -347,7 +347,29 @@ struct AdamSegs {
     float inv_sqrt_bc2[8]; // 1 / sqrt(1 - beta2^t)
     int nseg;
     float w1, w2, beta2, eps;  // 1 - beta1, 1 - beta2 (formed in double on the host), beta2, eps
+    const float* coef;     // g4s_adam_step_device: step_size[s] = coef[s], inv_sqrt_bc2[s] = coef[8 + s] (device memory,
+                           // written by adam_prep_kernel in front of this launch); NULL: the two arrays above
 };
+
+// g4s_adam_step_device: the step counts and learning rates live on the device, so that a captured launch (hipGraph) does
+// the right update at every replay.  One thread per segment: t <- t + 1, then the two bias-correction factors in double,
+// exactly as the host does for g4s_adam_step.
+struct AdamPrep {
+    float* step[8];   // per segment: torch's capturable state["step"] (a float32 scalar on the device), incremented here
+    const float* lr;  // [nseg] on the device
+    float* coef;      // [16] scratch on the device
+    int nseg;
+    double beta1, beta2;
+};
+__global__ void adam_prep_kernel(AdamPrep a) {
+    const int i = (int)threadIdx.x;
+    if (i >= a.nseg) return;
+    const float t = *a.step[i] + 1.0f;
+    *a.step[i] = t;
+    const double bc1 = 1.0 - pow(a.beta1, (double)t), bc2 = 1.0 - pow(a.beta2, (double)t);
+    a.coef[i] = (float)((double)a.lr[i] / bc1);
+    a.coef[8 + i] = (float)(1.0 / sqrt(bc2));
+}
 
 // One thread per 4 consecutive floats (16-byte accesses when the segment base is 16-byte aligned, which torch
 // allocations are; the tail and misaligned bases fall back to scalar accesses).
@@ -362,7 +384,8 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs a) {
     const float* g = a.g[s] + e0;
     float* m = a.m[s] + e0;
     float* v = a.v[s] + e0;
-    const float w1 = a.w1, w2 = a.w2, ss = a.step_size[s], ib = a.inv_sqrt_bc2[s];
+    const float w1 = a.w1, w2 = a.w2;
+    const float ss = a.coef ? a.coef[s] : a.step_size[s], ib = a.coef ? a.coef[8 + s] : a.inv_sqrt_bc2[s];
     const bool vec = e0 + 4 <= a.n[s] && (((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0;
     float pv[4], gv[4], mv[4], vv[4];
     const int cnt = vec ? 4 : (int)((a.n[s] - e0) < 4 ? (a.n[s] - e0) : 4);
@@ -470,6 +493,28 @@ extern "C" void g4s_densify_stats_launch_internal(int P, const float* grad, cons
     if (P <= 0) return;
     hipLaunchKernelGGL(g4s::densify_stats_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, P, grad, filter, radii,
                        accum, denom, max_radii);
+}
+
+extern "C" void g4s_adam_device_launch_internal(int nseg, float* const* params, const float* const* grads,
+                                                float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
+                                                const float* lr_dev, float* const* step_dev, float* coef_dev, double beta1,
+                                                double beta2, double eps, hipStream_t s) {
+    g4s::AdamPrep pr{};
+    pr.nseg = nseg; pr.lr = lr_dev; pr.coef = coef_dev; pr.beta1 = beta1; pr.beta2 = beta2;
+    g4s::AdamSegs a{};
+    a.nseg = nseg; a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2); a.beta2 = (float)beta2; a.eps = (float)eps;
+    a.coef = coef_dev;
+    long long blocks4 = 0;
+    for (int i = 0; i < nseg; i++) {
+        pr.step[i] = step_dev[i];
+        a.p[i] = params[i]; a.g[i] = grads[i]; a.m[i] = exp_avg[i]; a.v[i] = exp_avg_sq[i]; a.n[i] = numel[i];
+        a.first[i] = blocks4;
+        blocks4 += (numel[i] + 3) / 4;
+    }
+    for (int i = nseg; i <= 8; i++) a.first[i] = blocks4;
+    hipLaunchKernelGGL(g4s::adam_prep_kernel, dim3(1), dim3(8), 0, s, pr);  // (the counts advance even when all segments are empty)
+    if (blocks4 == 0) return;
+    hipLaunchKernelGGL(g4s::adam_kernel, dim3((unsigned)((blocks4 + 255) / 256)), dim3(256), 0, s, a);
 }
 
 extern "C" void g4s_adam_launch_internal(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,

@@ -125,12 +125,12 @@ class GaussianModel(DensifyMixin):
 
     # ---- optimisation ------------------------------------------------------------------------------
     def training_setup(self, training_args=None, position_lr=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
-                       rotation_lr=0.001, fused=None):
+                       rotation_lr=0.001, fused=None, capturable=False):
         """gaussian_model.py:248-266.  `training_args`: the reference's OptimizationParams-like object
         (position_lr_init/final/delay_mult/max_steps, feature_lr, opacity_lr, scaling_lr, rotation_lr, percent_dense);
         without it the keyword defaults (= arguments/__init__.py) apply.  `fused` (default: on for HIP tensors):
         one-kernel Adam (optim.FusedAdam) instead of torch.optim.Adam's foreach passes; same groups, names, lr, eps and
-        state layout."""
+        state layout.  `capturable`: step counts and learning rates on the device (for graphed.TrainStepGraph)."""
         position_lr_final, delay_mult, max_steps = position_lr / 100.0, 0.01, 30000
         if training_args is not None:
             ta = training_args
@@ -156,9 +156,9 @@ class GaussianModel(DensifyMixin):
             fused = self._xyz.is_cuda
         if fused:
             from .optim import FusedAdam
-            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15, capturable=capturable)
         else:
-            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, capturable=capturable)
 
     def update_learning_rate(self, iteration):
         """gaussian_model.py:268-274: the xyz group follows the exponential schedule; returns the new rate."""

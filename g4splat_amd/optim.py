@@ -14,6 +14,11 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
+    """capturable=True (extension, same meaning as torch.optim.Adam's): state["step"] is a float32 scalar ON THE DEVICE and
+    the learning rates are read from a device buffer, so that a step() captured in a HIP graph (graphed.TrainStepGraph)
+    does the right update at every replay.  Outside a capture step() uploads the groups' current `lr` itself; a replayed
+    graph cannot, so call `sync_lr()` before `graph.replay()` whenever a learning rate has changed."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, *, foreach=None,
                  maximize=False, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
@@ -27,13 +32,76 @@ class FusedAdam(torch.optim.Optimizer):
                         decoupled_weight_decay=decoupled_weight_decay)
         self._check_plain(defaults)
         super().__init__(params, defaults)
+        self._dev = {}  # capturable: (batch key, chunk) -> (lr_dev, last uploaded values, coef_dev)
 
     @staticmethod
     def _check_plain(group):
         if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False) or \
-                group.get("capturable", False) or group.get("differentiable", False) or group.get("decoupled_weight_decay", False):
-            raise ValueError("FusedAdam implements plain Adam only: weight_decay, amsgrad, maximize, capturable, "
-                             "differentiable and decoupled_weight_decay must keep their defaults")
+                group.get("differentiable", False) or group.get("decoupled_weight_decay", False):
+            raise ValueError("FusedAdam implements plain Adam only: weight_decay, amsgrad, maximize, differentiable and "
+                             "decoupled_weight_decay must keep their defaults")
+
+    def _batches(self, advance_host_step, need_grad=True):
+        """(betas, eps, device, capturable) -> [(param, grad or None, state, lr)], state created lazily like
+        torch.optim.Adam's.  need_grad: leave parameters without a gradient out (the plain path); the capturable path keeps
+        them as empty segments so that a parameter's slot in the device-side learning-rate buffer never moves."""
+        batches = {}
+        for group in self.param_groups:
+            self._check_plain(group)
+            cap = bool(group.get("capturable", False))
+            for p in group["params"]:
+                key = (group["betas"][0], group["betas"][1], group["eps"], p.device, cap)
+                if p.grad is None:
+                    if cap and not need_grad and p.requires_grad:
+                        batches.setdefault(key, []).append((p, None, self.state[p], float(group["lr"])))
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam: parameters must be CUDA tensors (use torch.optim.Adam on the host)")
+                if p.grad.is_sparse or p.dtype != torch.float32:
+                    raise RuntimeError("FusedAdam supports dense float32 parameters only")
+                st = self.state[p]
+                if len(st) == 0:  # same lazy state initialisation as torch.optim.Adam
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device) if cap else torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if cap and not st["step"].is_cuda:  # (a state dict loaded from a non-capturable optimiser)
+                    st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+                if advance_host_step and not cap:
+                    st["step"] += 1
+                for name in ("exp_avg", "exp_avg_sq"):
+                    if not st[name].is_contiguous():
+                        st[name] = st[name].contiguous()
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous")
+                batches.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"])))
+        return batches
+
+    def _dev_buffers(self, key, n, dev):
+        """capturable: per batch key, one learning rate per parameter slot (slot = position among the key's trainable
+        parameters), the values last uploaded, 16 floats of bias-correction scratch per chunk of eight and a dummy step."""
+        buf = self._dev.get(key)
+        if buf is None or buf[0].numel() != n:
+            chunks = (n + 7) // 8
+            buf = (torch.zeros(n, dtype=torch.float32, device=dev), [None] * n,
+                   torch.zeros(16 * chunks, dtype=torch.float32, device=dev), torch.zeros((), dtype=torch.float32, device=dev))
+            self._dev[key] = buf
+        return buf
+
+    @torch.no_grad()
+    def sync_lr(self):
+        """capturable: uploads the groups' current learning rates to the device buffer the (captured) step reads.  On the
+        current stream; call it before replaying a graph that contains step()."""
+        for key, items in self._batches(False, need_grad=False).items():
+            if not key[4]:
+                continue
+            with torch.cuda.device(key[3]):
+                lr_dev, last, _coef, _dummy = self._dev_buffers(key, len(items), key[3])
+                new = [s[3] for s in items]
+                if new != last:
+                    # from PAGEABLE memory: the runtime stages the floats before the call returns, so the host may change
+                    # its copy while the GPU is still iterations behind (a reused pinned buffer would race)
+                    lr_dev.copy_(torch.tensor(new, dtype=torch.float32))
+                    last[:] = new
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -43,41 +111,36 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         # (betas, eps, device) -> segments; the reference uses one setting for all groups => one launch per 8 tensors
-        batches = {}
-        for group in self.param_groups:
-            self._check_plain(group)
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda:
-                    raise RuntimeError("FusedAdam: parameters must be CUDA tensors (use torch.optim.Adam on the host)")
-                if p.grad.is_sparse or p.dtype != torch.float32:
-                    raise RuntimeError("FusedAdam supports dense float32 parameters only")
-                st = self.state[p]
-                if len(st) == 0:  # same lazy state initialisation as torch.optim.Adam
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                for name in ("exp_avg", "exp_avg_sq"):
-                    if not st[name].is_contiguous():
-                        st[name] = st[name].contiguous()
-                if not p.is_contiguous():
-                    raise RuntimeError("FusedAdam: parameters must be contiguous")
-                key = (group["betas"][0], group["betas"][1], group["eps"], p.device)
-                batches.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"])))
-        for (b1, b2, eps, dev), items in batches.items():
+        batches = self._batches(True, need_grad=False)
+        if any(k[4] for k in batches) and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        for (b1, b2, eps, dev, cap), items in batches.items():
             with torch.cuda.device(dev):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-                for i in range(0, len(items), 8):
+                if cap:
+                    lr_dev, _last, coef, dummy = self._dev_buffers((b1, b2, eps, dev, cap), len(items), dev)
+                for c, i in enumerate(range(0, len(items), 8)):
                     seg = items[i:i + 8]
                     k = len(seg)
-                    ptr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
-                    rc = lib.g4s_adam_step(
-                        k, ptr([s[0] for s in seg]), ptr([s[1] for s in seg]), ptr([s[2]["exp_avg"] for s in seg]),
-                        ptr([s[2]["exp_avg_sq"] for s in seg]), (ctypes.c_longlong * k)(*[s[0].numel() for s in seg]),
-                        (ctypes.c_double * k)(*[s[3] for s in seg]), (ctypes.c_int * k)(*[int(s[2]["step"]) for s in seg]),
-                        float(b1), float(b2), float(eps), stream)
+                    ptr = lambda ts: (ctypes.c_void_p * k)(*[(t.data_ptr() if t is not None else 0) for t in ts])
+                    if cap:
+                        if all(s[1] is None for s in seg):
+                            continue
+                        live = [s[1] is not None for s in seg]
+                        rc = lib.g4s_adam_step_device(
+                            k, ptr([s[0] for s in seg]), ptr([s[1] for s in seg]),
+                            ptr([s[2]["exp_avg"] if ok else None for s, ok in zip(seg, live)]),
+                            ptr([s[2]["exp_avg_sq"] if ok else None for s, ok in zip(seg, live)]),
+                            (ctypes.c_longlong * k)(*[(s[0].numel() if ok else 0) for s, ok in zip(seg, live)]),
+                            ctypes.c_void_p(lr_dev.data_ptr() + 4 * i),
+                            ptr([s[2]["step"] if ok else dummy for s, ok in zip(seg, live)]),  # (no gradient: t stays)
+                            ctypes.c_void_p(coef.data_ptr() + 64 * c), float(b1), float(b2), float(eps), stream)
+                    else:
+                        rc = lib.g4s_adam_step(
+                            k, ptr([s[0] for s in seg]), ptr([s[1] for s in seg]), ptr([s[2]["exp_avg"] for s in seg]),
+                            ptr([s[2]["exp_avg_sq"] for s in seg]), (ctypes.c_longlong * k)(*[s[0].numel() for s in seg]),
+                            (ctypes.c_double * k)(*[s[3] for s in seg]), (ctypes.c_int * k)(*[int(s[2]["step"]) for s in seg]),
+                            float(b1), float(b2), float(eps), stream)
                     if rc != 0:
                         raise RuntimeError(f"g4s_adam_step failed ({rc}): {_lib.last_error()}")
         return loss

@@ -364,3 +364,65 @@ def test_config3_densification_at_size_edits_a_material_share_of_the_rows(hip_li
         for P, c, s_, pr, n in report:
             print(f"\nC3 densify_and_prune at P={P}: cloned {c} ({100 * c / P:.1f} %), split {s_} ({100 * s_ / P:.1f} %), "
                   f"pruned {pr} ({100 * pr / P:.1f} %) -> {n} rows")
+
+
+def test_training_iteration_replayed_from_a_hip_graph_equals_the_eager_loop():
+    """graphed.TrainStepGraph: render + fused loss + regularisers + backward + densification statistics + FusedAdam step
+    (capturable: step counts and learning rates on the device) captured once and replayed, against the same iterations
+    issued eagerly from Python -- three cameras in turn, the xyz learning rate changing every iteration.  The kernels and
+    their order are the same, so parameters, Adam state and statistics must agree bit for bit; the capture's warm-up
+    iterations must leave no trace."""
+    from g4splat_amd.graphed import TrainStepGraph
+    from g4splat_amd.losses import geometry_regularizers
+    dev = torch.device("cuda", 0)
+    cams = _cams(dev)[:3]
+    g = torch.Generator(device=dev).manual_seed(3)
+    gts = [torch.rand((3, H, W), device=dev, generator=g) for _ in cams]
+
+    def body(out, gt):
+        loss, _l1, _s = photometric_loss(out["render"], gt, 0.2)
+        normal_mean, dist_mean = geometry_regularizers(out["rend_normal"], out["surf_normal"], out["rend_dist"])
+        return loss + 0.05 * normal_mean + 100.0 * dist_mean
+
+    def fresh():
+        m = _model(0, dev, jitter=True)
+        m.training_setup(capturable=True)
+        return m
+
+    pipe = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+    iters = 9
+    # eager
+    a = fresh()
+    losses_a = []
+    for it in range(iters):
+        a.update_learning_rate(it + 1)
+        out = render(cams[it % 3], a, pipe, bg)
+        loss = body(out, gts[it % 3])
+        loss.backward()
+        with torch.no_grad():
+            a.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
+        a.optimizer.step()
+        a.optimizer.zero_grad(set_to_none=True)
+        losses_a.append(float(loss))
+    # graph
+    b = fresh()
+    before = [p.detach().clone() for p in b.parameters()]
+    step = TrainStepGraph(b, body, cams[0], (3, H, W), instance_capacity=200_000)
+    for p, q in zip(b.parameters(), before):
+        assert torch.equal(p, q)  # the warm-up left no trace
+    assert all(float(st["step"]) == 0 for st in b.optimizer.state.values())
+    losses_b = []
+    for it in range(iters):
+        b.update_learning_rate(it + 1)
+        losses_b.append(float(step(cams[it % 3], gts[it % 3])))
+    assert not step.overflowed() and step.replays == iters
+    assert losses_a == losses_b, (losses_a, losses_b)
+    for name, p, q in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), a.parameters(), b.parameters()):
+        assert torch.equal(p, q), name
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+        assert float(sa["step"]) == float(sb["step"]) == iters
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom)
+    assert losses_a[-1] < losses_a[0]

@@ -2,7 +2,10 @@
 only: render() [HIP rasterizer + fused maps] -> fused L1+SSIM loss + normal-consistency and distortion regularisers
 (train_with_refine_depth.py:378-399) -> backward -> FusedAdam step + densification statistics.
 
-    python tools/train_iter_bench.py [--iters 40] [--torch-adam]
+    python tools/train_iter_bench.py [--iters 40] [--torch-adam] [--graph]
+
+--graph: the same iteration captured once in a HIP graph and replayed (g4splat_amd.graphed.TrainStepGraph; presized
+rasterizer state, FusedAdam with step counts and learning rates on the device): one launch from the host per iteration.
 
 Prints wall time per iteration and the per-kernel-group milliseconds from the library's profiling hooks."""
 import argparse
@@ -31,6 +34,8 @@ def main():
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused kernel")
+    ap.add_argument("--graph", action="store_true", help="replay the iteration from a HIP graph")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="leave the library's per-kernel event pairs off (they cost ~5 us each)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -42,7 +47,7 @@ def main():
         model._opacity.copy_(torch.logit(t(scene.opacities).clamp(1e-4, 1 - 1e-4)))
         model._features_rest.copy_(t(scene.shs[:, 1:, :]))
     model.active_sh_degree = 3
-    model.training_setup(fused=not a.torch_adam)
+    model.training_setup(fused=not a.torch_adam, capturable=a.graph)
     cams = []
     for c in synthetic.room_cameras(8, a.width, a.height, fovx_deg=90.0):
         cams.append(SimpleNamespace(image_width=a.width, image_height=a.height, FoVx=2 * math.atan(c.tanfovx),
@@ -64,11 +69,33 @@ def main():
             model.optimizer.step()
             model.optimizer.zero_grad(set_to_none=True)
 
+    if a.graph:
+        from g4splat_amd.diff_surfel_rasterization import _C
+        from g4splat_amd.graphed import TrainStepGraph
+        R, empty = 0, torch.empty(0, device=dev)
+        with torch.no_grad():
+            for cam in cams:
+                fw = _C.rasterize_gaussians(bg, model.get_xyz, empty, model.get_opacity, model.get_scaling, model.get_rotation,
+                                            1.0, empty, cam.world_view_transform, cam.full_proj_transform,
+                                            math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), a.height, a.width,
+                                            model.get_features, 3, cam.camera_center, False, False)
+                R = max(R, int(fw[0]))
+        del fw
+
+        def body(out, gt):
+            loss, _l1, _s = photometric_loss(out["render"], gt, 0.2)
+            normal_mean, dist_mean = geometry_regularizers(out["rend_normal"], out["surf_normal"], out["rend_dist"])
+            return loss + 0.05 * normal_mean + 100.0 * dist_mean
+        step = TrainStepGraph(model, body, cams[0], (3, a.height, a.width), instance_capacity=int(R * 1.3), pipe=pipe, bg=bg)
+
+        def iteration(i):  # noqa: F811
+            model.update_learning_rate(i + 1)
+            step(cams[i % 8], gts[i % 8])
     for i in range(8):
         iteration(i)
     torch.cuda.synchronize()
     lib.g4s_profile_reset()
-    lib.g4s_profile_enable(1)
+    lib.g4s_profile_enable(0 if (a.graph or a.no_kernel_timing) else 1)
     t0 = time.perf_counter()
     for i in range(a.iters):
         iteration(i)
@@ -82,7 +109,7 @@ def main():
         if cnt.value:
             ker[lib.g4s_profile_name(k).decode()] = round(ms.value / a.iters, 4)
     print(json.dumps({"P": a.P, "resolution": [a.width, a.height], "iters": a.iters, "ms_per_iteration": round(wall, 3),
-                      "optimizer": "torch.optim.Adam" if a.torch_adam else "FusedAdam",
+                      "optimizer": "torch.optim.Adam" if a.torch_adam else "FusedAdam", "hip_graph": bool(a.graph),
                       "library_kernels_ms_per_iteration": ker, "library_kernels_sum_ms": round(sum(ker.values()), 3)}))
 
 
