@@ -754,11 +754,11 @@ extern "C" int g4s_adam_step(int nseg, float* const* params, const float* const*
 
 extern "C" void g4s_adam_device_launch_internal(int nseg, float* const* params, const float* const* grads,
                                                 float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
-                                                const float* lr_dev, float* const* step_dev, float* coef_dev, double beta1,
+                                                const double* lr_dev, float* const* step_dev, float* coef_dev, double beta1,
                                                 double beta2, double eps, hipStream_t s);
 
 extern "C" int g4s_adam_step_device(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
-                                    float* const* exp_avg_sq, const long long* numel, const float* lr_dev,
+                                    float* const* exp_avg_sq, const long long* numel, const double* lr_dev,
                                     float* const* step_dev, float* coef_dev, double beta1, double beta2, double eps,
                                     void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

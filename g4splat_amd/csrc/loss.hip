@@ -356,7 +356,7 @@ struct AdamSegs {
 // exactly as the host does for g4s_adam_step.
 struct AdamPrep {
     float* step[8];   // per segment: torch's capturable state["step"] (a float32 scalar on the device), incremented here
-    const float* lr;  // [nseg] on the device
+    const double* lr; // [nseg] on the device (double, like the Python floats the host path divides)
     float* coef;      // [16] scratch on the device
     int nseg;
     double beta1, beta2;
@@ -367,7 +367,7 @@ __global__ void adam_prep_kernel(AdamPrep a) {
     const float t = *a.step[i] + 1.0f;
     *a.step[i] = t;
     const double bc1 = 1.0 - pow(a.beta1, (double)t), bc2 = 1.0 - pow(a.beta2, (double)t);
-    a.coef[i] = (float)((double)a.lr[i] / bc1);
+    a.coef[i] = (float)(a.lr[i] / bc1);
     a.coef[8 + i] = (float)(1.0 / sqrt(bc2));
 }
 
@@ -497,7 +497,7 @@ extern "C" void g4s_densify_stats_launch_internal(int P, const float* grad, cons
 
 extern "C" void g4s_adam_device_launch_internal(int nseg, float* const* params, const float* const* grads,
                                                 float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
-                                                const float* lr_dev, float* const* step_dev, float* coef_dev, double beta1,
+                                                const double* lr_dev, float* const* step_dev, float* coef_dev, double beta1,
                                                 double beta2, double eps, hipStream_t s) {
     g4s::AdamPrep pr{};
     pr.nseg = nseg; pr.lr = lr_dev; pr.coef = coef_dev; pr.beta1 = beta1; pr.beta2 = beta2;

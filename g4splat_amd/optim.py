@@ -82,7 +82,7 @@ class FusedAdam(torch.optim.Optimizer):
         buf = self._dev.get(key)
         if buf is None or buf[0].numel() != n:
             chunks = (n + 7) // 8
-            buf = (torch.zeros(n, dtype=torch.float32, device=dev), [None] * n,
+            buf = (torch.zeros(n, dtype=torch.float64, device=dev), [None] * n,
                    torch.zeros(16 * chunks, dtype=torch.float32, device=dev), torch.zeros((), dtype=torch.float32, device=dev))
             self._dev[key] = buf
         return buf
@@ -100,7 +100,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if new != last:
                     # from PAGEABLE memory: the runtime stages the floats before the call returns, so the host may change
                     # its copy while the GPU is still iterations behind (a reused pinned buffer would race)
-                    lr_dev.copy_(torch.tensor(new, dtype=torch.float32))
+                    lr_dev.copy_(torch.tensor(new, dtype=torch.float64))
                     last[:] = new
 
     @torch.no_grad()
@@ -132,7 +132,7 @@ class FusedAdam(torch.optim.Optimizer):
                             ptr([s[2]["exp_avg"] if ok else None for s, ok in zip(seg, live)]),
                             ptr([s[2]["exp_avg_sq"] if ok else None for s, ok in zip(seg, live)]),
                             (ctypes.c_longlong * k)(*[(s[0].numel() if ok else 0) for s, ok in zip(seg, live)]),
-                            ctypes.c_void_p(lr_dev.data_ptr() + 4 * i),
+                            ctypes.c_void_p(lr_dev.data_ptr() + 8 * i),
                             ptr([s[2]["step"] if ok else dummy for s, ok in zip(seg, live)]),  # (no gradient: t stays)
                             ctypes.c_void_p(coef.data_ptr() + 64 * c), float(b1), float(b2), float(eps), stream)
                     else:

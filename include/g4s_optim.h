@@ -32,14 +32,14 @@ int g4s_adam_step(int nseg, float* const* params, const float* const* grads, flo
 
 /*
  * The same update with the step counts and learning rates read from DEVICE memory, for launches captured in a hipGraph
- * (a replay must advance t and may see a new learning rate): lr_dev [nseg] float32 on the device; step_dev = HOST array of
+ * (a replay must advance t and may see a new learning rate): lr_dev [nseg] float64 on the device (doubles, like `lr` above); step_dev = HOST array of
  * nseg device pointers to float32 scalars holding t BEFORE the call (torch's capturable state["step"]); each is
  * incremented by one on the device, then used.  coef_dev: 16 floats of device scratch owned by the caller for the
  * lifetime of the launch (the bias-correction factors, computed in double on the device like g4s_adam_step does on the
  * host).  Two launches.
  */
 int g4s_adam_step_device(int nseg, float* const* params, const float* const* grads, float* const* exp_avg,
-                         float* const* exp_avg_sq, const long long* numel, const float* lr_dev, float* const* step_dev,
+                         float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float* const* step_dev,
                          float* coef_dev, double beta1, double beta2, double eps, void* stream);
 
 /*

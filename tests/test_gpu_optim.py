@@ -49,6 +49,39 @@ def test_matches_torch_adam_over_many_steps(hip_lib):
             assert (sa[key].cpu() - want).abs().max() <= 1e-5 * want.abs().max(), (n, key)
 
 
+def test_capturable_mode_equals_the_plain_mode(hip_lib):
+    """capturable=True: step counts (float32 scalars, torch's convention) and learning rates live on the device
+    (g4s_adam_step_device: the bias corrections are formed in double by a one-block kernel instead of by the host).  Same
+    update, bit for bit, over 40 steps with a changing learning rate and with a parameter that sits out some steps -- its
+    step count must not advance and nobody's slot in the learning-rate buffer may move."""
+    dev = "cuda:0"
+    pa, ga = _groups(dev)
+    pb, gb = _groups(dev)
+    a = FusedAdam(ga, lr=0.0, eps=1e-15)
+    b = FusedAdam(gb, lr=0.0, eps=1e-15, capturable=True)
+    g = torch.Generator().manual_seed(4)
+    for it in range(40):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if i == 2 and it % 4 == 1:
+                x.grad = y.grad = None
+                continue
+            grad = (torch.randn(x.shape, generator=g) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=g)))).to(dev)
+            x.grad, y.grad = grad.clone(), grad.clone()
+        a.param_groups[0]["lr"] = b.param_groups[0]["lr"] = 0.00016 * (0.97 ** it)
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    for x, y, n in zip(pa, pb, NAMES):
+        assert torch.equal(x, y), n
+        sa, sb = a.state[x], b.state[y]
+        assert sb["step"].is_cuda and float(sa["step"]) == float(sb["step"]) == (30 if n == "f_rest" else 40)
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    # the state dict moves to torch.optim.Adam(capturable=True) and back
+    c = torch.optim.Adam(_groups(dev)[1], lr=0.0, eps=1e-15, capturable=True)
+    c.load_state_dict(b.state_dict())
+    assert all(float(st["step"]) in (30.0, 40.0) for st in c.state.values())
+
+
 def test_state_surgery_like_densification(hip_lib):
     """cat_tensors_to_optimizer (gaussian_model.py:528-549) replaces a parameter and extends its moments; the
     optimiser must carry on with the edited state.  Misaligned / odd-sized tensors take the scalar path."""
