@@ -426,3 +426,28 @@ def test_training_iteration_replayed_from_a_hip_graph_equals_the_eager_loop():
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
     assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom)
     assert losses_a[-1] < losses_a[0]
+    # densification changes P: the graph is captured again for the new set and carries on (the reference densifies every
+    # 100 iterations, train_with_refine_depth.py:573-590); split children are drawn from torch's generator: seed both alike
+    for m in (a, b):
+        torch.manual_seed(7)
+        with torch.no_grad():
+            m.densify_and_prune(2e-6, 0.005, 3.0, 20)
+    n_new = a.get_xyz.shape[0]
+    assert n_new == b.get_xyz.shape[0] and n_new != P
+    step = TrainStepGraph(b, body, cams[0], (3, H, W), instance_capacity=300_000)
+    for it in range(iters, iters + 4):
+        a.update_learning_rate(it + 1)
+        out = render(cams[it % 3], a, pipe, bg)
+        loss = body(out, gts[it % 3])
+        loss.backward()
+        with torch.no_grad():
+            a.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
+        a.optimizer.step()
+        a.optimizer.zero_grad(set_to_none=True)
+        b.update_learning_rate(it + 1)
+        lb = step(cams[it % 3], gts[it % 3])
+        assert float(loss) == float(lb), it
+    for name, p, q in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), a.parameters(), b.parameters()):
+        assert torch.equal(p, q), name
+    assert all(float(a.optimizer.state[p]["step"]) == float(b.optimizer.state[q]["step"]) == iters + 4
+               for p, q in zip(a.parameters(), b.parameters()))
