@@ -404,7 +404,7 @@ def test_training_iteration_replayed_from_a_hip_graph_equals_the_eager_loop():
             a.add_densification_stats(out["viewspace_points"], out["visibility_filter"], out["radii"])
         a.optimizer.step()
         a.optimizer.zero_grad(set_to_none=True)
-        losses_a.append(float(loss))
+        losses_a.append(float(loss.detach()))
     # graph
     b = fresh()
     before = [p.detach().clone() for p in b.parameters()]
@@ -446,7 +446,7 @@ def test_training_iteration_replayed_from_a_hip_graph_equals_the_eager_loop():
         a.optimizer.zero_grad(set_to_none=True)
         b.update_learning_rate(it + 1)
         lb = step(cams[it % 3], gts[it % 3])
-        assert float(loss) == float(lb), it
+        assert float(loss.detach()) == float(lb), it
     for name, p, q in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), a.parameters(), b.parameters()):
         assert torch.equal(p, q), name
     assert all(float(a.optimizer.state[p]["step"]) == float(b.optimizer.state[q]["step"]) == iters + 4
