@@ -269,7 +269,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dmeans3D = make((P, 3), "dL_dmeans3D", **fopt)
         dL_dmeans2D = make((P, 3), "dL_dmeans2D", **fopt)
         dL_dcolors = make((P, NUM_CHANNELS), "dL_dcolors", **fopt)
-        dL_dnormal = make((P, 3), **fopt)
+        dL_dnormal = None  # scratch of the reference's K7 -> K8 hand-over (rasterize_points.cu:176), never returned: not written
         dL_dopacity = make((P, 1), "dL_dopacity", **fopt)
         dL_dtransMat = make((P, 9), "dL_dtransMat", **fopt)
         if split:
