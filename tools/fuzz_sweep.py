@@ -3,6 +3,7 @@ test_fuzz_small_scenes, other seeds, plus needle / hair splats), both backward k
 a robustness sweep to run when the kernels change.
 
     python tools/fuzz_sweep.py [first_seed] [count] [kind]
+FUZZ_BIG=1: frames of 640x360 .. 1601x1203 with 50 k .. 300 k Gaussians (the same random generator).
 Criterion: tests/common.py::assert_parity (guard bars + threshold-margin proof); FUZZ_CONTRACT_BARS=1 or FUZZ_COT=1
 (sparse cotangents) fall back to the north-star bars (1e-4 / 1e-3)."""
 import os
@@ -27,6 +28,10 @@ for seed in range(first, first + count):
     W = int(rng.choice([1, 7, 16, 33, 100, 161, 250, 400]))
     H = int(rng.choice([1, 5, 16, 47, 96, 130, 300]))
     P = int(rng.choice([1, 2, 17, 300, 2000, 6000, 20000]))
+    if os.environ.get("FUZZ_BIG"):  # mid-size frames: thousands of tiles, lists hundreds deep (between the small fuzz and S2)
+        W = int(rng.choice([640, 1000, 1333, 1601]))
+        H = int(rng.choice([360, 480, 750, 1203]))
+        P = int(rng.choice([50_000, 120_000, 300_000]))
     D = int(rng.integers(0, 4))
     inp = scene_inputs(P=P, W=W, H=H, seed=seed, D=D, bg=tuple(rng.uniform(0, 1, 3)),
                        scale_mul=float(rng.choice([0.02, 0.05, 0.5, 1.0, 4.0, 20.0])),
