@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
     st.Tt = inside ? 1.0f : 0.0f;
     st.T_done = 1.0f;
     uint32_t n_blended = 0;  // wave-uniform: (entry, this quadrant) pairs some pixel blended = the backward's visits
+    uint32_t n_entries = 0;  // wave-uniform: staged entries (of this wave's share of every batch) that some pixel blended
 
     for (int b0 = 0; b0 < n; b0 += FWD_BATCH) {
         // end if the entire tile is saturated (forward.cu:327)
@@ -197,16 +198,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
         }
         // contribution mask for the backward: one byte per staged entry, bit q = quadrant q blended it
         __syncthreads();
+        uint32_t nib = 0;
         if ((int)threadIdx.x < m) {
             const int g = (int)threadIdx.x >> 6, b = (int)threadIdx.x & 63;
-            const uint32_t nib = (uint32_t)((s_hit[g][0] >> b) & 1ull) | ((uint32_t)((s_hit[g][1] >> b) & 1ull) << 1) |
-                                 ((uint32_t)((s_hit[g][2] >> b) & 1ull) << 2) | ((uint32_t)((s_hit[g][3] >> b) & 1ull) << 3);
+            nib = (uint32_t)((s_hit[g][0] >> b) & 1ull) | ((uint32_t)((s_hit[g][1] >> b) & 1ull) << 1) |
+                  ((uint32_t)((s_hit[g][2] >> b) & 1ull) << 2) | ((uint32_t)((s_hit[g][3] >> b) & 1ull) << 3);
             if (nib) a.qhit[r0 + b0 + threadIdx.x] = (uint8_t)nib;
         }
+        n_entries += (uint32_t)__popcll(__ballot(nib != 0));  // (this wave's 64 staged entries)
     }
     // the backward's work in this tile, for its longest-first ordering (tile_order_kernel reads (start, end) pairs)
     __syncthreads();
-    if (lane == 0) (&s_hit[0][0])[wv] = n_blended;
+    // the backward's cost of a tile ~ 111 instructions per visit + 78 per contributing entry (reduction, record): the
+    // ordering key is visits + 3/4 entries
+    if (lane == 0) (&s_hit[0][0])[wv] = n_blended + ((3u * n_entries) >> 2);
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long* v = &s_hit[0][0];
