@@ -439,7 +439,11 @@ def main():
                                    "v_fma_f32 1.73-1.97 ns per wave instruction and SIMD (4 cycles at the clock the part "
                                    "sustains under that load), v_pk_fma_f32 2.45 ns"}
         if valu and valu["simd_issue_utilisation"] is not None:
+            # the roof the kernel is closer to -- or neither: a small frame (S1: one wave per SIMD) runs at a third of
+            # the issue rate and 2 % of the HBM peak; that is latency, not a roofline
             bound = "valu" if valu["simd_issue_utilisation"] > achieved / HBM_PEAK_GBS else "hbm"
+            if max(valu["simd_issue_utilisation"], achieved / HBM_PEAK_GBS) < 0.5:
+                bound = "latency"
         else:
             bound = "unknown"  # no counters for this workload / kernel: the HBM fraction below is all this run can say
         traffic = int((2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024) if pk and "FETCH_SIZE" in pk and "WRITE_SIZE" in pk else None

@@ -44,6 +44,14 @@ if len(sys.argv) >= 4:
             for c in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):  # VALU issue rate (the blend kernels' real bound)
                 if c in agg[k]:
                     kern[key][c] = round(agg[k][c] / max(cnt[k][c], 1), 1)
+    # frames small enough for the four-wave backward throughout (<= 768 tiles, e.g. S1) never launch blend_bwd_kernel:
+    # there the four-wave kernel IS the blend backward
+    hot = "blend_bwd_hot_kernel"
+    hk = next((k for k in agg if k.split("(")[0].endswith(hot) or k.startswith(hot)), None)
+    if "blend_bwd" not in kern and hk and "FETCH_SIZE" in agg[hk] and "WRITE_SIZE" in agg[hk]:
+        kern["blend_bwd"] = {c: round(agg[hk][c] / max(cnt[hk][c], 1), 1)
+                             for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE") if c in agg[hk]}
+        kern["blend_bwd"]["kernel"] = hot
     json.dump({"workload": sys.argv[3],
                "provenance": (sys.argv[4] if len(sys.argv) >= 5 else "rocprofv3 --pmc passes (commit not recorded)") +
                              " -- static: collected by tools/profile_gpu.sh, not measured in the bench run that quotes it",
