@@ -42,15 +42,26 @@ def presized(state, workspace=None):
 
 
 def _forward(*fwd_args):
-    """(outputs of _C.rasterize_gaussians, backward workspace or None) through the presized entry when a slot is active."""
+    """(outputs of _C.rasterize_gaussians, backward context or None) through the presized entry when a slot is active.
+    The backward context is (workspace, state, the state's generation after this forward)."""
     slot = getattr(_slot, "value", None)
     if slot is None:
         return _C.rasterize_gaussians(*fwd_args), None
-    return _C.rasterize_gaussians_presized(slot[0], *fwd_args), slot[1]
+    state = slot[0]
+    out = _C.rasterize_gaussians_presized(state, *fwd_args)
+    state.generation = getattr(state, "generation", 0) + 1
+    return out, (slot[1], state, state.generation)
 
 
-def _backward(workspace):
+def _backward(bctx):
     def call(*bwd_args):
+        if bctx is None:
+            return _C.rasterize_gaussians_backward(*bwd_args)
+        workspace, state, generation = bctx
+        if getattr(state, "generation", generation) != generation:
+            # the forward's scratch IS the PresizedState: a later forward through the same state has overwritten it
+            raise RuntimeError("backward of a view whose PresizedState has been used by another forward since "
+                               "(run a view's backward before its slot renders the next view)")
         return _C.rasterize_gaussians_backward(*bwd_args, out=None if workspace is None else {"workspace": workspace})
     return call
 

@@ -298,3 +298,33 @@ def test_multi_view_batch_through_render_and_autograd_on_two_streams():
     pipe.release_hooks()
     # and the slot really was used: the second run's forward states are the pipeline's
     assert lib is not None and all(int(st.status[1].item()) > 0 for st in pipe.states)
+
+
+def test_backward_refuses_a_presized_state_that_rendered_another_view_since():
+    """The forward's scratch of a view rendered inside a slot IS the slot's PresizedState: forward(A), forward(B) through
+    the same state, backward(A) would read B's lists.  The autograd node keeps the state's generation and raises."""
+    import math
+    from types import SimpleNamespace
+    import numpy as np
+    from g4splat_amd import synthetic
+    from g4splat_amd.diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer, presized, _C
+    dev = torch.device("cuda", 0)
+    P, W, H = 5000, 160, 96
+    scene, cam = synthetic.scene_random(P, seed=1, width=W, height=H)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    xyz = t(scene.means3D).requires_grad_(True)
+    args = dict(means2D=torch.zeros_like(xyz), opacities=t(scene.opacities), shs=t(scene.shs), scales=t(scene.scales),
+                rotations=t(scene.rotations))
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                                       bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=t(cam.world_view_transform),
+                                       projmatrix=t(cam.full_proj_transform), sh_degree=3, campos=t(cam.camera_center),
+                                       prefiltered=False, debug=False)
+    rast = GaussianRasterizer(rs)
+    state = _C.PresizedState(P, W, H, 400_000, dev)
+    with presized(state):
+        c1, _r1, _d1 = rast(xyz, **args)
+        c2, _r2, _d2 = rast(xyz, **args)
+        with pytest.raises(RuntimeError, match="used by another forward since"):
+            c1.sum().backward()
+        c2.sum().backward()  # the latest forward's backward is fine
+    assert xyz.grad is not None and torch.isfinite(xyz.grad).all() and xyz.grad.abs().max() > 0
