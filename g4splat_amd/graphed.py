@@ -126,3 +126,4 @@ class TrainStepGraph:
 
     def overflowed(self):
         return int(self.state.status[3].item()) != 0
+
