@@ -75,10 +75,11 @@ class TrainStepGraph:
 
     def _snapshot(self):
         g = self.gaussians
-        tensors = [p for grp in g.optimizer.param_groups for p in grp["params"]]
-        fresh = [p for p in tensors if len(g.optimizer.state[p]) == 0]  # their state is created by the warm-up: zero it after
-        for p in tensors:
-            tensors = tensors + [v for v in g.optimizer.state[p].values() if torch.is_tensor(v)]
+        params = [p for grp in g.optimizer.param_groups for p in grp["params"]]
+        fresh = [p for p in params if len(g.optimizer.state[p]) == 0]  # their state is created by the warm-up: zero it after
+        tensors = list(params)
+        for p in params:
+            tensors += [v for v in g.optimizer.state[p].values() if torch.is_tensor(v)]
         tensors += [t for t in (g.xyz_gradient_accum, g.denom, g.max_radii2D) if torch.is_tensor(t) and t.numel()]
         with torch.no_grad():
             return [(t, t.detach().clone()) for t in tensors], fresh
