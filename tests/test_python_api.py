@@ -127,3 +127,25 @@ def test_debug_snapshot_covers_the_split_sh_node(tmp_path, monkeypatch):
     dump = torch.load(tmp_path / "snapshot_fw.dump")
     pair = [a for a in dump if isinstance(a, tuple)]
     assert len(pair) == 1 and pair[0][0].shape == (P, 1, 3) and pair[0][1].shape == (P, 15, 3)
+
+
+def test_presized_context_nests_and_is_per_thread():
+    """diff_surfel_rasterization.presized: the active (state, workspace) is what the innermost `with` set, is restored on
+    exit (also when the body raises) and is not seen by other threads (the autograd engine's workers take what the forward
+    stored in the node instead)."""
+    import threading
+    import g4splat_amd.diff_surfel_rasterization as dsr
+    a, b = object(), object()
+    assert getattr(dsr._slot, "value", None) is None
+    with dsr.presized(a, "wa"):
+        assert dsr._slot.value == (a, "wa")
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(getattr(dsr._slot, "value", None)))
+        th.start(); th.join()
+        assert seen == [None]
+        with pytest.raises(ValueError):
+            with dsr.presized(b):
+                assert dsr._slot.value == (b, None)
+                raise ValueError("x")
+        assert dsr._slot.value == (a, "wa")
+    assert dsr._slot.value is None
