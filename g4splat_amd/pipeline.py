@@ -33,7 +33,9 @@ exits; by then that view's backward has been issued), so the accumulations happe
 the sums are bit-identical to the sequential loop's.  `after_previous_view()` is the same wait for user code (densification
 statistics, running means).  The waits sit at the very end of a view's backward: nothing of the overlap is lost.
 (Keep the leaves' .grad buffers persistent -- zero_grad(set_to_none=False) -- so that no gradient tensor moves from one
-stream's allocator pool to another stream's reader; a view's backward must be issued before its slot is used again.)
+stream's allocator pool to another stream's reader; a view's backward must be issued before its slot is used again -- the
+autograd node checks that and raises otherwise.  Anything else produced inside a slot and read on another stream after
+join(), an image kept for logging say, follows torch's rule for cross-stream use: `t.record_stream(reader_stream)`.)
 
 Every slot owns a PresizedState (g4s_rasterizer_forward_presized: no host read-back, so the one host thread never blocks),
 a backward workspace and -- through torch's per-stream allocator pools -- its output tensors.  The backward OVERWRITES its
