@@ -331,6 +331,14 @@ def test_config2_room_views(hip_lib, oracle_mod, capsys, view, D):
     assert rep["R"] > 300_000
 
 
+@pytest.mark.parametrize("view", range(8))
+def test_config4_every_training_view(hip_lib, oracle_mod, capsys, view):
+    """BASELINE config 4 (8 training views of the room, one per GPU): every one of the eight views a rank can be handed,
+    at the stand-in size (300 k surfels, 1200x680, SH degree 3), against the oracle with the full gate."""
+    rep, h, o = full_size_case(oracle_mod, capsys, f"C4 view {view}", room_inputs(300_000, 1200, 680, view, 8), seed=10 + view)
+    assert rep["R"] > 200_000
+
+
 def test_config5_three_million_surfels(hip_lib, oracle_mod, capsys):
     """BASELINE config 5 stand-in (S5): 3 M surfels, SH degree 3, all seven `allmap` cotangents non-zero (what the
     depth / normal / distortion regularisers of train_with_refine_depth.py:391-396 produce)."""
