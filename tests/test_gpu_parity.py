@@ -324,9 +324,9 @@ def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys, view):
     assert rep["R"] > 4_000_000
 
 
-@pytest.mark.parametrize("view,D", [(0, 3), (2, 0), (4, 3)])
+@pytest.mark.parametrize("view,D", [(0, 3), (1, 3), (2, 0), (3, 3), (4, 3)])
 def test_config2_room_views(hip_lib, oracle_mod, capsys, view, D):
-    """BASELINE config 2 stand-in (S2): 300 k surfels, 1200x680, three of the five views, SH degree 0 and 3."""
+    """BASELINE config 2 stand-in (S2): 300 k surfels, 1200x680, all five input views, SH degree 0 and 3."""
     rep, h, o = full_size_case(oracle_mod, capsys, f"S2 view {view} D={D}", room_inputs(300_000, 1200, 680, view, 5, D=D))
     assert rep["R"] > 300_000
 
