@@ -80,7 +80,8 @@ for seed in range(first, first + count):
                 # default criterion: the test suite's -- guard bars (~10x the measured error) on everything that is not
                 # explained by a decision threshold within 1e-5 of its value in the oracle (tests/common.py)
                 assert_parity(h, o, inp, oracle_mod, tag=tag, scale_aware=scene_scale != 1.0)
-                if o["R"] > 0 and mode == "policy":
+                # (the list check walks every tile in Python: minutes per mid-size frame; the suite does it at S2 / S3 size)
+                if o["R"] > 0 and mode == "policy" and not os.environ.get("FUZZ_BIG"):
                     check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
                 continue
             assert h["R"] == o["R"], "R"
@@ -121,7 +122,7 @@ for seed in range(first, first + count):
             kind_s = "CULLING BUG" if cured and str(ex) in ("color", "others") else "threshold flip" if str(ex) in ("color", "others") else "other"
             bad.append((tag, str(ex), kind_s, npx))
             print("MISMATCH", tag, ex, kind_s, f"{npx} pixels", flush=True)
-    if (seed - first) % (10 if os.environ.get("FUZZ_BIG") else 100) == 9 if os.environ.get("FUZZ_BIG") else (seed - first) % 100 == 99:
+    if os.environ.get("FUZZ_BIG") or (seed - first) % 100 == 99:
         print(f"{seed - first + 1} scenes, {len(bad)} mismatches", flush=True)
 _lib.set_option("bwd_hot_threshold", _lib.OPTION_UNSET)
 print(f"done: {count} scenes x 2 backward kernels, {len(bad)} mismatches")
