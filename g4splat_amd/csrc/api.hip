@@ -507,7 +507,7 @@ static int rasterizer_backward_impl(
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer))
         return fail(G4S_ERR_INVALID_ARGUMENT, "state buffers must not be NULL");
     if (!dL_dpix || !dL_depths || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D ||
-        !dL_dtransMat || !dL_dscale || !dL_drot || (M > 0 && !dL_dsh) || (shs_rest && M > 1 && !dL_dsh_rest))
+        !dL_dscale || !dL_drot || (M > 0 && !dL_dsh) || (shs_rest && M > 1 && !dL_dsh_rest))
         return fail(G4S_ERR_INVALID_ARGUMENT, "NULL gradient pointer");
     if (workspace_bytes < g4s_rasterizer_backward_workspace(P, R) || !workspace)
         return fail(G4S_ERR_INVALID_ARGUMENT, "workspace too small");

@@ -271,7 +271,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dcolors = make((P, NUM_CHANNELS), "dL_dcolors", **fopt)
         dL_dnormal = None  # scratch of the reference's K7 -> K8 hand-over (rasterize_points.cu:176), never returned: not written
         dL_dopacity = make((P, 1), "dL_dopacity", **fopt)
-        dL_dtransMat = make((P, 9), "dL_dtransMat", **fopt)
+        # out["dL_dtransMat"] = False: the caller does not want it (the autograd node when no T matrices were given: the
+        # reference computes dL_dtransMat as an intermediate there and nobody reads it) -- 36 B per Gaussian K8 need not write
+        if given.get("dL_dtransMat", None) is False:
+            given.pop("dL_dtransMat")
+            dL_dtransMat = None
+        else:
+            dL_dtransMat = make((P, 9), "dL_dtransMat", **fopt)
         if split:
             dL_dsh = (make((P, 1, 3), "dL_dsh_dc", **fopt), make((P, M - 1, 3), "dL_dsh_rest", **fopt))
         else:

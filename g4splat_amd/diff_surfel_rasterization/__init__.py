@@ -55,14 +55,18 @@ def _forward(*fwd_args):
 
 def _backward(bctx):
     def call(*bwd_args):
+        # (cov3Ds_precomp / transMat not given: its gradient is an intermediate of the native backward that nobody reads)
+        out = {"dL_dtransMat": False} if bwd_args[7].numel() == 0 else {}
         if bctx is None:
-            return _C.rasterize_gaussians_backward(*bwd_args)
+            return _C.rasterize_gaussians_backward(*bwd_args, out=out or None)
         workspace, state, generation = bctx
         if getattr(state, "generation", generation) != generation:
             # the forward's scratch IS the PresizedState: a later forward through the same state has overwritten it
             raise RuntimeError("backward of a view whose PresizedState has been used by another forward since "
                                "(run a view's backward before its slot renders the next view)")
-        return _C.rasterize_gaussians_backward(*bwd_args, out=None if workspace is None else {"workspace": workspace})
+        if workspace is not None:
+            out["workspace"] = workspace
+        return _C.rasterize_gaussians_backward(*bwd_args, out=out or None)
     return call
 
 

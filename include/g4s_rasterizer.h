@@ -100,7 +100,8 @@ size_t g4s_rasterizer_backward_workspace(int P, int R);
  *     dL_dmean2D[P,3]  (densification surrogate, backward.cu:637-640; .z = 0)
  *     dL_dnormal[P,3] (view-space normal gradient; may be NULL, the reference's binding never
  *     returns it), dL_dopacity[P], dL_dcolor[P,3], dL_dmean3D[P,3],
- *     dL_dtransMat[P,9], dL_dsh[P,M,3] (if M > 0), dL_dscale[P,2], dL_drot[P,4]
+ *     dL_dtransMat[P,9] (may be NULL: an intermediate nobody reads unless T matrices were handed in precomputed),
+ *     dL_dsh[P,M,3] (if M > 0), dL_dscale[P,2], dL_drot[P,4]
  * Deterministic (no floating-point atomics), unlike the reference.
  * Returns G4S_OK or a negative G4S_ERR_*.
  */
