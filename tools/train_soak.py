@@ -3,7 +3,11 @@ hundred iterations with the reference's schedule in miniature -- SH degree raise
 prune every 100 from iteration 100 (gaussian_model.py:628-647), opacity reset once -- and the run reports loss,
 PSNR against the targets, the Gaussian count and whether anything became non-finite.
 
-    python tools/train_soak.py [--iters 600] [--P 120000] [--width 640] [--height 480]"""
+    python tools/train_soak.py [--iters 600] [--P 120000] [--width 640] [--height 480] [--graph]
+
+--graph: the iterations between two schedule events (every 100th iteration: SH degree, densification, opacity reset, the
+distortion weight) are replayed from a HIP graph (g4splat_amd.graphed.TrainStepGraph), which is captured again after every
+event; the event iterations themselves run eagerly.  Same kernels in the same order: the log must equal the eager run's."""
 import argparse
 import json
 import math
@@ -34,8 +38,10 @@ def main():
     ap.add_argument("--P", type=int, default=120_000)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--graph", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    torch.manual_seed(0)  # (densify_and_split draws its children from torch's generator: two runs are comparable)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
     scene = synthetic.scene_room(a.P, seed=0, scale_mean=0.04)
     cams = []
@@ -66,7 +72,7 @@ def main():
     shs0 = np.zeros_like(scene.shs[keep])
     model = build(scene.means3D[keep] + rng.normal(0, 0.02, (keep.size, 3)).astype(np.float32), scene.scales[keep] * 2.0,
                   scene.rotations[keep], np.full_like(scene.opacities[keep], 0.3), shs0, 0)
-    model.training_setup()
+    model.training_setup(capturable=a.graph)
     extent = 5.0
 
     def evaluate():
@@ -79,10 +85,41 @@ def main():
     densify_ms = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step, captures = None, 0
+
+    def capture(first_it):
+        """A graph for the iterations from `first_it` up to the next schedule event."""
+        from g4splat_amd.diff_surfel_rasterization import _C
+        from g4splat_amd.graphed import TrainStepGraph
+        R, empty = 0, torch.empty(0, device=dev)
+        with torch.no_grad():
+            for cam in cams:
+                fw = _C.rasterize_gaussians(bg, model.get_xyz, empty, model.get_opacity, model.get_scaling, model.get_rotation, 1.0,
+                                            empty, cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx * 0.5),
+                                            math.tan(cam.FoVy * 0.5), a.height, a.width, model.get_features, model.active_sh_degree,
+                                            cam.camera_center, False, False)
+                R = max(R, int(fw[0]))
+        w_dist = 100.0 if first_it > a.iters // 2 else 0.0
+
+        def body(out, gt):
+            loss, _l1, _s = photometric_loss(out["render"], gt, 0.2)
+            nm, dm = geometry_regularizers(out["rend_normal"], out["surf_normal"], out["rend_dist"])
+            return loss + 0.05 * nm + (w_dist * dm if w_dist else 0.0)
+        return TrainStepGraph(model, body, cams[0], (3, a.height, a.width), instance_capacity=int(R * 1.5) + 1024, pipe=pipe, bg=bg)
+
     for it in range(1, a.iters + 1):
         if it % 100 == 0 and model.active_sh_degree < 3:
             model.active_sh_degree += 1
         i = (it * 5) % 8
+        if a.graph and it % 100 != 0:
+            if step is None:
+                step = capture(it)
+                captures += 1
+            step(cams[i], targets[i])
+            continue
+        if step is not None:
+            assert not step.overflowed(), it
+            step = None
         out = render(cams[i], model, pipe, bg)
         loss, _l1, _s = photometric_loss(out["render"], targets[i], 0.2)
         nm, dm = geometry_regularizers(out["rend_normal"], out["surf_normal"], out["rend_dist"])
@@ -112,6 +149,7 @@ def main():
     for p in (model._xyz, model._scaling, model._rotation, model._opacity, model._features_dc, model._features_rest):
         finite = finite and bool(torch.isfinite(p).all())
     log["finite"] = finite
+    log["hip_graph"] = {"captures": captures} if a.graph else False
     log["P_end"] = int(model.get_xyz.shape[0])
     log["max_memory_GB"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 3)
     print(json.dumps(log))
