@@ -4,13 +4,27 @@
 A "step" is one pass of the hot path over one training view: one
 `_C.rasterize_gaussians` + one `_C.rasterize_gaussians_backward` on
 synthetic data already resident in HBM; with N > 1 ranks every rank renders its own view
-of the replicated scene and the step also all-reduces the parameter gradients over RCCL
-(one view per GPU, weak scaling).
+of the replicated scene and the step also exchanges the parameter gradients over RCCL
+(SURVEY.md 8(e)).
 
 Workload at N=1 (BASELINE.json metric "rasterized Gaussians/s fwd+bwd @1600x1200"):
 S3 = configs[2] stand-in: 1.5 M surfels on the faces of a 6x4x3 m room, 1600x1200, SH degree 3.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (re-exec through
+torch.distributed.run on 127.0.0.1); under torch.distributed.run it uses the ranks it is given.
+
+  --scaling weak    (default) one view per rank per step: the job renders N views per step.
+  --scaling strong  SURVEY.md 8(e)'s form: 8 views per optimiser step in total, 8/N per rank, accumulated
+                    locally (views in flight on HIP streams, gradients summed in program order), then ONE exchange.
+
+Timing ("median of the steps after the warm-ups"): the K steps sit between barrier + synchronize on
+both sides and every step is bracketed by HIP events on the launch stream.  `ms_per_step` / `value` come from the
+MEDIAN step; `mean_ms` (host clock over the whole region / K), `max_ms` and `per_step_ms` are printed next to it, and
+when the mean exceeds the median by more than 10 % the pass is marked `disturbed` (with the steps that did it) and
+repeated, at most three times; every attempt is listed.  The warm-up is by state, not by count: after the W steps the
+driver asks for, stepping continues until three consecutive 10-step windows agree within 2 % (at most ~1 s).
 
 prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
 `roofline` for the dominant kernel and `cpu_baseline` (the CPU oracle timed on the host
@@ -20,14 +34,12 @@ import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
 
 WORKLOADS = {
     # name: (P, W, H, SH degree, #views)
@@ -38,10 +50,55 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024           # 256 CUs x 4 SIMDs
-CLOCK_HZ = 2.4e9       # engine clock
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
+STRONG_VIEWS = 8       # C4 = 8 training views per optimiser step over 1/2/4/8 GPUs
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="s3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0,
+                    help="after the headline pass, keep stepping for at least this long (and >= 500 steps) and report "
+                         "the settled throughput as `sustained` (0 = skip)")
+    ap.add_argument("--no-gc-freeze", action="store_true",
+                    help="leave Python's cyclic garbage collector as it is (default: gc.collect() + gc.freeze() before "
+                         "the warm-up, so that a full collection over the interpreter's ~10^6 long-lived objects cannot "
+                         "land inside a timed pass; host-side hygiene, the GPU work is unchanged)")
+    ap.add_argument("--no-settle", action="store_true", help="skip the state-based part of the warm-up")
+    ap.add_argument("--attempts", type=int, default=3, help="how often a disturbed headline pass is repeated")
+    ap.add_argument("--views-in-flight", type=int, default=3,
+                    help="N = 1 only, reported next to the headline (never as `value`): throughput with up to this many "
+                         "INDEPENDENT views in flight on separate HIP streams (multi-view batches; 0 / 1 = skip)")
+    ap.add_argument("--presized", action="store_true",
+                    help="use g4s_rasterizer_forward_presized (no host read-back; extension) instead of the "
+                         "reference-shaped forward -- for the step-time comparison in DESIGN.md, not the default")
+    return ap.parse_args(argv)
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: become the launcher (one rank per GPU, rendezvous on
+    127.0.0.1, a free port), exactly the command the driver would have issued."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (task environment)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def build_scene(name, device):
+    import numpy as np
+    import torch
     from g4splat_amd import synthetic
     P, W, H, D, nviews = WORKLOADS[name]
     if name == "s1":
@@ -72,28 +129,23 @@ def algorithmic_bytes(kernel, P, V, R, N, K, M, tiles, tile_bits):
     }.get(kernel)
 
 
+def summarize_steps(per_step_ms, mean_ms):
+    """median / mean / max of one timed pass and whether something other than the work itself landed in it."""
+    med = statistics.median(per_step_ms)
+    disturbed = mean_ms > 1.1 * med
+    return {"median_ms": med, "mean_ms": mean_ms, "max_ms": max(per_step_ms), "min_ms": min(per_step_ms),
+            "disturbed": bool(disturbed),
+            # the steps that carry the excess: more than 1.5x the median
+            "disturbed_steps": [i for i, t in enumerate(per_step_ms) if t > 1.5 * med] if disturbed else []}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="s3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
-    ap.add_argument("--sustained-seconds", type=float, default=1.0,
-                    help="after the headline pass, keep stepping for at least this long (and >= 500 steps) and report "
-                         "the settled throughput as `sustained` (0 = skip)")
-    ap.add_argument("--no-gc-freeze", action="store_true",
-                    help="leave Python's cyclic garbage collector as it is (default: gc.collect() + gc.freeze() after the "
-                         "warm-up, so that a full collection over the interpreter's ~10^6 long-lived objects cannot land "
-                         "inside a timed pass; host-side hygiene, the GPU work is unchanged)")
-    ap.add_argument("--views-in-flight", type=int, default=3,
-                    help="N = 1 only, reported next to the headline (never as `value`): throughput with up to this many "
-                         "INDEPENDENT views in flight on separate HIP streams (multi-view batches; 0 / 1 = skip)")
-    ap.add_argument("--presized", action="store_true",
-                    help="use g4s_rasterizer_forward_presized (no host read-back; extension) instead of the "
-                         "reference-shaped forward -- for the step-time comparison in DESIGN.md, not the default")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)  # does not return
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,10 +157,11 @@ def main():
     if os.environ.get("G4S_BENCH_ONE_DEVICE"):
         local_rank = 0
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    if args.scaling == "strong" and STRONG_VIEWS % world:
+        raise SystemExit(f"--scaling strong shards {STRONG_VIEWS} views per step: N must divide {STRONG_VIEWS}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -122,54 +175,98 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from g4splat_amd import _lib, build
-    build.build()
+    if rank == 0:
+        build.build()
+    if dist is not None:
+        dist.barrier()
     lib = _lib.load()
+    build_id = lib.g4s_version().decode().split("build ")[-1]
     from g4splat_amd.diff_surfel_rasterization import _C
 
     scene, cams, dev, dcams, (P, W, H, D) = build_scene(args.workload, device)
     N = W * H
+    strong = args.scaling == "strong"
+    if strong and len(dcams) != STRONG_VIEWS:
+        raise SystemExit(f"--scaling strong needs a workload with {STRONG_VIEWS} views")
+    views_per_rank = STRONG_VIEWS // world if strong else 1
     bg = torch.zeros(3, device=device)
     empty = torch.empty(0, device=device)
     g = torch.Generator(device=device).manual_seed(1)
     dL_dcolor = torch.randn((3, H, W), device=device, generator=g)
     dL_dothers = torch.randn((7, H, W), device=device, generator=g)
 
-    # one persistent flat fp32 bucket holds the parameter gradients of this rank's view (xyz, SH,
+    # one persistent flat fp32 bucket holds the parameter gradients of this rank's view(s) (xyz, SH,
     # opacity, scale, rotation = 58 floats per Gaussian at SH degree 3) plus the densification side channel (per-view
     # ||grad_means2D||, visibility); the backward writes straight into views of it (`out=`).  The exchange is
     # g4splat_amd.parallel.OwnerReduce (three collectives per step on persistent buffers: radii MAX + sizes, all_to_all
     # of visible rows to their owners, grouped in-place all_gather of the reduced shards) or, as the fallback,
     # RowSparseAllReduce (MAX all-reduce of the radii, then one SUM all-reduce of the rows visible on some rank).
-    grad_out = side = rmax = reducer = None
-    # G4S_BENCH_EXCHANGE=owner (default): OwnerReduce -- all_to_all of this rank's visible rows to index-shard owners +
-    # all_gather of the reduced shards (g4splat_amd/parallel.py); =allreduce: the visible-rows /
-    # dense SUM all-reduce of round 1.  If the owner exchange fails on this machine's RCCL during warm-up the bench
-    # falls back to the all-reduce and says so in config.parallelism.
+    # G4S_BENCH_EXCHANGE=owner (default) | allreduce.  If the owner exchange fails on this machine's RCCL during
+    # warm-up the bench falls back to the all-reduce -- agreed on by all ranks -- and says so (`exchange.why`).
     exchange = os.environ.get("G4S_BENCH_EXCHANGE", "owner")
-    if dist is not None:
-        from g4splat_amd.parallel import OwnerReduce, RowSparseAllReduce
-        M = int(dev["sh"].shape[1])
-        shapes = [("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 2)),
-                  ("dL_drotations", (P, 4)), ("side", (P, 2))]
+    exchange_why = "requested" if "G4S_BENCH_EXCHANGE" in os.environ else "default"
+    M = int(dev["sh"].shape[1])
+    shapes = [("dL_dmeans3D", (P, 3)), ("dL_dsh", (P, M, 3)), ("dL_dopacity", (P, 1)), ("dL_dscales", (P, 2)),
+              ("dL_drotations", (P, 4)), ("side", (P, 2))]
+
+    def make_bucket():
         offs, o = [], 0
         for _n, shp in shapes:
             offs.append(o)
             o += (int(np.prod(shp)) + 63) // 64 * 64  # 256-B aligned views
-        bucket = torch.zeros(o, device=device)
-        views = {n: bucket[b:b + int(np.prod(shp))].view(shp) for (n, shp), b in zip(shapes, offs)}
+        flat = torch.zeros(o, device=device)
+        views = {n: flat[b:b + int(np.prod(shp))].view(shp) for (n, shp), b in zip(shapes, offs)}
+        return flat, views
+
+    grad_out = side = rmax = reducer = bucket = None
+    if dist is not None or strong:
+        bucket, views = make_bucket()
         side = views.pop("side")
         grad_out = views
         rmax = torch.zeros((P,), dtype=torch.int32, device=device)
+    if dist is not None:
+        from g4splat_amd.parallel import OwnerReduce, RowSparseAllReduce
         row_views = [v.view(P, -1) for v in grad_out.values()] + [side]
         reducer = OwnerReduce(row_views) if exchange == "owner" else RowSparseAllReduce(bucket, row_views)
     exchanged_rows = []
     exchange_events = None  # list of (start, stop) events while the instrumented pass runs
 
     pstate = None
+    pipe = None
+    slot_buckets = None
+    vis_union = torch.zeros((P,), dtype=torch.bool, device=device) if strong else None
 
-    def step(i):
+    def views_of_step(i):
+        """The camera indices THIS rank renders in step i."""
+        if strong:  # shard_views: rank r renders views r, r + N, ... of the step's 8
+            return [(rank + j * world) % len(dcams) for j in range(views_per_rank)]
+        return [(rank + i * world) % len(dcams)]
+
+    def exchange_step(radii, gm2):
+        """weak scaling: statistics of the one view, then the collectives (the owner exchange's begin() has been issued
+        right after the forward)."""
+        nonlocal exchange_events
+        ev = None
+        if exchange_events is not None:  # instrumented pass only: GPU time of the exchange, this rank
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        torch.linalg.vector_norm(gm2[:, :2], dim=1, out=side[:, 0])
+        side[:, 1] = radii > 0
+        if exchange == "owner":
+            reducer.finish()  # (reducer.max_radii = MAX over the ranks of the radii, from begin()'s collective)
+            exchanged_rows.append(reducer.last_rows_sent)
+        else:
+            rmax.copy_(radii)
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+            reducer.reduce(rmax > 0)
+            exchanged_rows.append(reducer.last_rows)
+        if ev is not None:
+            ev[1].record()
+            exchange_events.append(ev)
+
+    def step_weak(i):
         nonlocal pstate
-        cam = dcams[(rank + i * world) % len(dcams)]
+        cam = dcams[views_of_step(i)[0]]
         if args.presized and pstate is not None:
             fw = _C.rasterize_gaussians_presized(pstate, bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
                                                  dev["rotations"], 1.0, empty, cam["view"], cam["proj"], cam["tanfovx"],
@@ -187,32 +284,82 @@ def main():
                                                 dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
                                                 img, False, out=grad_out)
         if dist is not None:
+            exchange_step(radii, grads[0])
+        return [(R, radii)]
+
+    def step_strong(i):
+        """One optimiser step of SURVEY.md 8(e)'s form: this rank's 8/N views go through a ViewPipeline (presized forward,
+        up to three views in flight on HIP streams); every view's backward writes its slot's own gradient bucket, which
+        is added to the step's bucket in program order (the accumulating stream waits for the previous view's slot:
+        bit-identical to the sequential loop); the exchange's begin() is issued right after the LAST view's forward (the
+        union of the views' visible sets is known then) so that its collective hides behind that view's backward."""
+        nonlocal exchange_events
+        vs = views_of_step(i)
+        L = len(vs)
+        fwd_done, radii_all, res = [], [], []
+        for j, c in enumerate(vs):
+            cam = dcams[c]
+            with pipe.slot(j) as (state, work):
+                sflat, sviews, sside = slot_buckets[j % pipe.k]
+                fw = _C.rasterize_gaussians_presized(state, bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
+                                                     dev["rotations"], 1.0, empty, cam["view"], cam["proj"],
+                                                     cam["tanfovx"], cam["tanfovy"], H, W, dev["sh"], D, cam["campos"],
+                                                     False, False)
+                radii = fw[3]
+                e = torch.cuda.Event()
+                e.record()
+                fwd_done.append(e)
+                radii_all.append(radii)
+                if j == L - 1:
+                    cur = torch.cuda.current_stream(device)
+                    for e2 in fwd_done[:-1]:
+                        cur.wait_event(e2)  # forwards issued long ago: no stall
+                    torch.gt(radii_all[0], 0, out=vis_union)
+                    rmax.copy_(radii_all[0])
+                    for r2 in radii_all[1:]:
+                        vis_union.logical_or_(r2 > 0)
+                        torch.maximum(rmax, r2, out=rmax)
+                    if dist is not None and exchange == "owner":
+                        reducer.begin(vis_union, radii=rmax)
+                out = dict(sviews)
+                out["workspace"] = work
+                grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
+                                                        1.0, empty, cam["view"], cam["proj"], cam["tanfovx"],
+                                                        cam["tanfovy"], dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"],
+                                                        fw[4], fw[0], fw[5], fw[6], False, out=out)
+                # per-view densification statistics BEFORE any reduction (gaussian_model.py:649-651), into the slot's side
+                torch.linalg.vector_norm(grads[0][:, :2], dim=1, out=sside[:, 0])
+                sside[:, 1] = radii > 0
+                pipe.after_previous_view()  # the sums below happen view after view, in program order
+                if j == 0:
+                    bucket.copy_(sflat)
+                else:
+                    bucket.add_(sflat)
+                res.append((fw[0], radii))
+        pipe.join()
+        if dist is not None:
             ev = None
-            if exchange_events is not None:  # instrumented pass only: GPU time of the exchange, this rank
+            if exchange_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            gm2 = grads[0]
-            torch.linalg.vector_norm(gm2[:, :2], dim=1, out=side[:, 0])
-            side[:, 1] = radii > 0
             if exchange == "owner":
-                reducer.finish()  # (reducer.max_radii = MAX over the ranks of the radii, from begin()'s collective)
+                reducer.finish()
                 exchanged_rows.append(reducer.last_rows_sent)
             else:
-                rmax.copy_(radii)
                 dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
                 reducer.reduce(rmax > 0)
                 exchanged_rows.append(reducer.last_rows)
             if ev is not None:
                 ev[1].record()
                 exchange_events.append(ev)
-        return R, radii
+        return res
+
+    step = step_strong if strong else step_weak
 
     # Host hygiene: a generation-2 collection of CPython's cyclic GC walks every long-lived object of the process (torch,
     # numpy, the scene: ~50 ms here) and lands wherever the allocation counters trip -- measured as ONE 53-ms stall in a
-    # 500-step pass, i.e. the whole difference between the 20-step headline and the "sustained" rate of round 2.  Long-
-    # running loops freeze the startup heap; so does this one -- BEFORE the warm-up steps, so that no host pause sits between
-    # the warm-up and the timed pass (a GPU left idle for the 0.1 s a collection takes starts the timed steps from a lower
-    # power state).  The collections that still happen are timed and reported.
+    # 500-step pass.  Long-running loops freeze the startup heap; so does this one -- BEFORE the warm-up steps, so that no
+    # host pause sits between the warm-up and the timed pass.  The collections that still happen are timed and reported.
     import gc
     gc_ms = [0.0, 0]
     gc_t0 = [0.0]
@@ -229,8 +376,32 @@ def main():
         gc.collect()
         gc.freeze()
 
-    # warm-up (also measures V and R per view outside the timed region)
+    # ---- warm-up (also measures V and R per view outside the timed region) ------------------------------------------
     Vs, Rs = {}, {}
+
+    def note(i, res):
+        for c, (R, radii) in zip(views_of_step(i), res):
+            if c not in Vs:
+                Vs[c] = int((radii > 0).sum().item())
+                Rs[c] = int(R)
+
+    if strong:
+        # the pipeline's capacity comes from a reference-shaped forward of every view this rank renders
+        for c in views_of_step(0):
+            cam = dcams[c]
+            fw = _C.rasterize_gaussians(bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0,
+                                        empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"], H, W, dev["sh"],
+                                        D, cam["campos"], False, False)
+            Vs[c], Rs[c] = int((fw[3] > 0).sum().item()), int(fw[0])
+            del fw
+        from g4splat_amd.pipeline import ViewPipeline
+        pipe = ViewPipeline(P, W, H, int(max(Rs.values()) * 1.25) + 4096, device, k=min(3, views_per_rank))
+        slot_buckets = []
+        for _ in range(pipe.k):
+            sflat, sviews = make_bucket()
+            sside = sviews.pop("side")
+            slot_buckets.append((sflat, sviews, sside))
+        torch.cuda.synchronize()
     if dist is not None and exchange == "owner":
         try:
             step(0)
@@ -239,64 +410,111 @@ def main():
         except Exception as ex:  # e.g. an RCCL build without uneven all_to_all
             print(f"[bench] owner exchange failed on rank {rank}: {ex}; falling back to all-reduce", file=sys.stderr)
             ok = torch.zeros(1, device=device)
+            exchange_why = f"owner exchange failed in warm-up on some rank ({type(ex).__name__}: {str(ex)[:200]})"
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0:
-            exchange = "allreduce(fallback)"
+            exchange = "allreduce"
+            if exchange_why in ("default", "requested"):
+                exchange_why = "owner exchange failed in warm-up on another rank"
             reducer = RowSparseAllReduce(bucket, row_views)
     for i in range(max(args.warmup, 1)):
-        R, radii = step(i)
-        c = (rank + i * world) % len(dcams)
-        Vs[c] = int((radii > 0).sum().item())
-        Rs[c] = int(R)
-    for i in range(len(dcams)):  # make sure every view that the timed steps use has its V known
-        c = (rank + i * world) % len(dcams)
-        if c not in Vs and i < args.steps:
-            R, radii = step(i)
-            Vs[c] = int((radii > 0).sum().item())
-            Rs[c] = int(R)
+        note(i, step(i))
+    for i in range(min(len(dcams), args.steps)):  # make sure every view that the timed steps use has its V known
+        if any(c not in Vs for c in views_of_step(i)):
+            note(i, step(i))
+    if strong:
+        assert not pipe.overflowed(), "presized capacity overflow"
 
-    if args.presized:  # capacity from the warm-up's instance counts, with head-room
+    if args.presized and not strong:  # capacity from the warm-up's instance counts, with head-room
         pstate = _C.PresizedState(P, W, H, int(max(Rs.values()) * 1.25) + 4096, device)
         step(0)
         torch.cuda.synchronize()
         assert pstate.status.tolist()[3] == 0
+
+    def agree_max(x):
+        """MAX over the ranks of a host float (every rank gets the same value back)."""
+        if dist is None:
+            return x
+        tt = torch.tensor([x], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # Warm-up by state: a cold box keeps changing for a while after the first kernels (clocks, the allocator's pools,
+    # page tables) -- step in windows of ~10 steps until three in a row agree within 2 %, at most ~1 s.
+    settle = {"extra_steps": 0, "windows_ms_per_step": [], "settled": None}
+    if not args.no_settle:
+        t_begin = time.perf_counter()
+        wins = []
+        k = 0
+        # a window holds the same mix of views every time: one full cycle of the views (weak), a few whole steps (strong)
+        wlen = max(2, 10 // views_per_rank) if strong else (len(dcams) if len(dcams) >= 4 else 10)
+        while True:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(wlen):
+                step(k)
+                k += 1
+            torch.cuda.synchronize()
+            wins.append(agree_max((time.perf_counter() - t0) / wlen * 1e3))
+            last = wins[-3:]
+            if len(last) == 3 and (max(last) - min(last)) <= 0.02 * min(last):
+                settle["settled"] = True
+                break
+            if agree_max(time.perf_counter() - t_begin) > 1.0 or len(wins) >= 60:
+                settle["settled"] = False
+                break
+        settle["extra_steps"] = k
+        settle["windows_ms_per_step"] = [round(w, 4) for w in wins]
+
     timing = not args.no_kernel_timing
     lib.g4s_profile_reset()
+    mem0 = torch.cuda.memory_stats(device)
 
     def timed_steps(with_events):
-        """EXACTLY args.steps steps between barrier + synchronize on both sides.  with_events: the library brackets
-        every kernel group with a pair of HIP events on the launch stream (per-kernel durations for the roofline);
-        those ~20 extra packets per step cost GPU time themselves, so the headline pass runs without them and the
-        instrumented pass repeats the same steps afterwards."""
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; one HIP event on the launch stream
+        behind every step (one packet per step: ~2 us of a ~2 ms step) gives the per-step GPU durations.
+        with_events: the library ALSO brackets every kernel group with a pair of HIP events (per-kernel durations for
+        the roofline); those ~20 extra packets per step cost GPU time themselves, so the headline pass runs without
+        them and the instrumented pass repeats the same steps afterwards.
+        -> (host seconds over the region, MAX over the ranks; per-step ms, element-wise MAX over the ranks)."""
         lib.g4s_profile_enable(1 if with_events else 0)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        per_step = []
+        evs[0].record()
         for i in range(args.steps):
-            ts = time.perf_counter()
             step(i)
-            if os.environ.get("G4S_BENCH_PER_STEP"):
-                torch.cuda.synchronize()
-                per_step.append(round((time.perf_counter() - ts) * 1e3, 2))
+            evs[i + 1].record()
         torch.cuda.synchronize()
-        if per_step and rank == 0:
-            print("per-step ms:", per_step, file=sys.stderr)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         lib.g4s_profile_enable(0)
-        return dt
+        per = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+        if dist is not None:
+            tt = torch.tensor([dt] + per, device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt, per = float(tt[0].item()), [float(x) for x in tt[1:].tolist()]
+        return dt, per
 
-    elapsed = timed_steps(False)            # the headline: value / ms_per_step (the contract's K steps)
+    # ---- the headline: the contract's K steps; repeated (and said so) when something else landed in them -----------
+    attempts = []
+    for _a in range(max(1, args.attempts)):
+        elapsed, per_step = timed_steps(False)
+        summ = summarize_steps(per_step, elapsed / args.steps * 1e3)
+        summ["per_step_ms"] = [round(t, 4) for t in per_step]
+        attempts.append(summ)
+        if not summ["disturbed"]:
+            break
+    head = attempts[-1]
+    mem1 = torch.cuda.memory_stats(device)
 
-    # Sustained throughput.  The headline's K steps last ~40 ms; the blend kernels hold the VALU at its issue limit and
-    # the part lowers its clock after ~0.2 s of that.  The reference's loop is thousands of iterations, so the settled
-    # rate is reported next to the headline: the same step, issued back to back right behind the headline pass (no
-    # pause anywhere), for >= --sustained-seconds and >= 500 steps; the engine clock is sampled from sysfs on the way.
+    # Sustained throughput: the same step, issued back to back right behind the headline pass (no pause anywhere), for
+    # >= --sustained-seconds and >= 500 steps; the engine clock is sampled from sysfs on the way.
     sustained = None
     if args.sustained_seconds > 0:
         sclk = []
@@ -308,20 +526,13 @@ def main():
         n_s, units_s = 0, 0
         # every rank must run the same number of steps (each one holds collectives): the count comes from the slowest
         # rank's headline time; the pass repeats the headline's K steps (same views) over and over
-        el = elapsed
-        if dist is not None:
-            tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        n_target = max(500, int(math.ceil(args.sustained_seconds / max(el / args.steps, 1e-6))))
-        first = []
+        n_target = max(500 // views_per_rank, int(math.ceil(args.sustained_seconds / max(head["median_ms"] * 1e-3, 1e-6))))
         reader = None
         marks = []  # host time every 50 steps: the reference-shaped forward waits for its read-back, so the host runs at
+        every = max(1, 50 // views_per_rank)
         for i in range(n_target):   # most one step ahead of the GPU and these times follow the GPU's progress
-            if i % 50 == 0:
+            if i % every == 0:
                 marks.append(time.perf_counter())
-            if i < 10:
-                first.append(time.perf_counter())
             if i == (3 * n_target) // 4 and rank == 0:
                 # one sysfs read of the engine clock, on a side thread: the read blocks for tens of ms inside the driver
                 # (the GIL is released meanwhile), and it must happen while the GPU is under load
@@ -334,7 +545,7 @@ def main():
                 reader = threading.Thread(target=_read)
                 reader.start()
             step(i % args.steps)
-            units_s += Vs[(rank + (i % args.steps) * world) % len(dcams)]
+            units_s += sum(Vs[c] for c in views_of_step(i % args.steps))
             n_s += 1
         if reader is not None:
             reader.join()
@@ -342,11 +553,8 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        dt_s = time.perf_counter() - t0
+        dt_s = agree_max(time.perf_counter() - t0)
         if dist is not None:
-            tt = torch.tensor([dt_s], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_s = float(tt.item())
             uu = torch.tensor([units_s], device=device, dtype=torch.float64)
             dist.all_reduce(uu)
             units_s = int(uu.item())
@@ -356,32 +564,58 @@ def main():
                      "clock_source": ("sysfs pp_dpm_sclk (the DPM level in force, not a cycle count) read once on a side "
                                       "thread three quarters into the pass" if sclk else
                                       "sysfs pp_dpm_sclk not readable on this box"),
-                     "ms_first_steps": [round((b - a) * 1e3, 3) for a, b in zip(first, first[1:])],
-                     "ms_per_step_by_50_steps": [round((b - a) / 50 * 1e3, 4) for a, b in zip(marks, marks[1:])],
+                     f"ms_per_step_by_{every}_steps": [round((b - a) / every * 1e3, 4) for a, b in zip(marks, marks[1:])],
                      "host_gc": {"collections": gc_ms[1], "ms_total": round(gc_ms[0], 2),
-                                 "startup_heap": "as is" if args.no_gc_freeze else "frozen after the warm-up (gc.freeze)"},
+                                 "startup_heap": "as is" if args.no_gc_freeze else "frozen before the warm-up (gc.freeze)"},
                      "note": "same step as the headline, issued back to back right behind it (no pause)"}
 
     exchange_ms = None
+    exchange_pieces = None
     if timing:                              # same steps again, instrumented: kernels_ms / roofline (+ the exchange at N > 1)
         exchange_events = [] if dist is not None else None
+        if dist is not None and exchange == "owner":
+            reducer.timing = True
         # (runs right behind the sustained pass: the per-kernel durations are those of the settled clock)
-        elapsed_events = timed_steps(True)
+        elapsed_events, _per = timed_steps(True)
         if exchange_events:
             exchange_ms = sum(a.elapsed_time(b) for a, b in exchange_events) / len(exchange_events)
         exchange_events = None
+        if dist is not None and exchange == "owner":
+            exchange_pieces = {k: round(v, 4) for k, v in reducer.read_timers().items()}
+            reducer.timing = False
     else:
         elapsed_events = None
 
-    units = sum(Vs[(rank + i * world) % len(dcams)] for i in range(args.steps))
-    inst = sum(Rs[(rank + i * world) % len(dcams)] for i in range(args.steps))
+    units = sum(Vs[c] for i in range(args.steps) for c in views_of_step(i))
+    inst = sum(Rs[c] for i in range(args.steps) for c in views_of_step(i))
     if dist is not None:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         uu = torch.tensor([units, inst], device=device, dtype=torch.float64)
         dist.all_reduce(uu)
         units, inst = int(uu[0].item()), int(uu[1].item())
+
+    exchange_info = None
+    if dist is not None:
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            rccl_version = None
+        exchange_info = {
+            "backend": backend, "rccl_version": rccl_version,
+            "rccl_ranks": dist.get_world_size(),  # from the communicator, not from the command line
+            "ran": ("owner-reduce: MAX all-reduce [P + N^2] int32 + uneven all_to_all of visible rows + grouped in-place "
+                    "all_gather of the reduced shards" if exchange == "owner" else
+                    "visible-rows all-reduce: MAX all-reduce of the radii + one SUM all-reduce of the union's rows"),
+            "why": exchange_why,
+            "coalesced_gather": bool(getattr(reducer, "_coalesce", False)) if exchange == "owner" else None,
+            "ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None,
+            "ms_pieces": exchange_pieces,
+            "pieces_note": ("HIP-event pairs on rank 0 in the instrumented pass; begin_local + max_all_reduce are issued "
+                            "right after the forward and overlap the backward, `ms_per_step` covers what follows the "
+                            "backward (statistics, pack, all_to_all, accumulate, all_gather)"),
+            "bytes_per_rank": dict(getattr(reducer, "last_bytes", {})) or None,
+            "rows_sent_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows else None),
+            "buffer_allocations": getattr(reducer, "allocations", None),
+        }
 
     if rank != 0:
         if dist is not None:
@@ -398,6 +632,7 @@ def main():
                 kernels_ms[lib.g4s_profile_name(k).decode()] = ms.value / cnt.value
         lib.g4s_profile_reset()
 
+    step_ms = head["median_ms"]
     # roofline of the dominant kernel (rank 0's view mix)
     roofline = None
     if kernels_ms:
@@ -405,17 +640,17 @@ def main():
                   key=lambda k: kernels_ms[k])
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         tile_bits = max(1, math.ceil(math.log2(tiles + 1)))
-        views = [(0 + i * world) % len(dcams) for i in range(args.steps)]
-        Vm = sum(Vs[c] for c in views) / len(views)
-        Rm = sum(Rs[c] for c in views) / len(views)
+        vlist = [c for i in range(args.steps) for c in views_of_step(i)]
+        Vm = sum(Vs[c] for c in vlist) / len(vlist)
+        Rm = sum(Rs[c] for c in vlist) / len(vlist)
         K = (D + 1) ** 2
         B = algorithmic_bytes(dom, P, Vm, Rm, N, K, 16, tiles, tile_bits)
         achieved = B / (kernels_ms[dom] * 1e-3) / 1e9
         # What binds the kernel.  `achieved` / `peak` / `frac` are the contract's HBM figures (SURVEY.md 8(d) bytes of
         # one launch / its HIP-event duration, measured in this run).  The blend kernels are NOT bound by HBM but by
         # VALU issue: `valu` says so with numbers -- wave-level VALU instructions per launch come from the committed
-        # rocprofv3 PMC passes of this build (they cannot be read in-process; `source` names the file and the commit it
-        # was taken at), the duration is this run's.
+        # rocprofv3 PMC passes (they cannot be read in-process; the file carries the build id of the library it was
+        # collected on and `traffic_matches_build` says whether that is the library timed here), the duration is this run's.
         pmc = pmc_profile(args.workload)
         pk = (pmc or {}).get("kernels", {}).get(dom)
         valu = None
@@ -428,11 +663,21 @@ def main():
             # SIMD cycles (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) / counted instructions -- so nothing is assumed
             # about the clock; at or below ~4.2 the SIMDs do nothing but issue VALU instructions.
             cpi = (pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS / insts) if pk.get("GRBM_GUI_ACTIVE") else None
+            issue = round(min(1.0, 4.0 / cpi), 4) if cpi else None
+            # how much of that issue rate does arithmetic on live pixels: lanes with a contributing pixel / 64 per
+            # VALU instruction of the entry loop (profiles/r04_lane_util_model.txt, measured on recorded S3 frames), and
+            # the part's FP32 rate counts an FMA on all 64 lanes every 4 cycles as 128 flop
+            lane = (pmc or {}).get("useful_lane_frac", {}).get(dom)
             valu = {"wave_instructions_per_launch": int(insts),
                     "cycles_per_instruction_profiled": round(cpi, 3) if cpi else None,
                     "full_rate_cycles_per_instruction": 4.0,
                     # share of the SIMDs' issue slots the launch used, clock-free: 1.0 when cpi <= 4
-                    "simd_issue_utilisation": round(min(1.0, 4.0 / cpi), 4) if cpi else None,
+                    "simd_issue_utilisation": issue,
+                    "frac_of_scalar_issue": issue,
+                    "useful_lane_frac": lane,
+                    # instructions x 64 lanes x useful share, as a fraction of lanes x cycles the launch had: what is
+                    # left of the FP32 peak if every instruction were an FMA (an upper bound: many are not)
+                    "frac_of_fp32_peak": (round(issue * lane, 4) if (issue is not None and lane is not None) else None),
                     "ns_per_instruction_this_run": round(t * SIMDS / insts * 1e9, 4),
                     "microbenchmark_ns_per_v_fma_f32": [1.73, 1.97],
                     "calibration": "tools/micro/valu_rate.hip on MI355X (profiles/r03_valu_rate.txt): back-to-back "
@@ -446,25 +691,36 @@ def main():
                 bound = "latency"
         else:
             bound = "unknown"  # no counters for this workload / kernel: the HBM fraction below is all this run can say
-        traffic = int((2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024) if pk and "FETCH_SIZE" in pk and "WRITE_SIZE" in pk else None
-        # whole step against the HBM roofline: every kernel's 8(d) bytes / the step time of this run
+        hbm = lambda q: int((2.0 * q["FETCH_SIZE"] + q["WRITE_SIZE"]) * 1024) if q and "FETCH_SIZE" in q and "WRITE_SIZE" in q else None
+        traffic = hbm(pk)
+        # whole step against the HBM roofline: every kernel's 8(d) bytes / the step time of this run, and next to it the
+        # bytes the kernels of THIS build actually moved (sum of the PMC tables: this build's 2-pass tile partition moves
+        # far less than the 6-pass 64-bit sort the 8(d) table prices)
         B_step = (P * 60 + Vm * (12 * K + 76) + Rm * 12 + Rm * 24 * ((32 + tile_bits + 7) // 8) + Rm * 8 + tiles * 8
                   + 2 * (Rm * 76 + N * 60) + Vm * 72 + Vm * (44 + 12 * K + 72 + 36 + 3) + P * 52 + P * 12 * 16 + Vm * 12 * K)
-        step_ms = elapsed / args.steps * 1e3
+        moved = [hbm(q) for q in (pmc or {}).get("kernels", {}).values()]
+        moved = sum(m for m in moved if m) if moved and all(m is not None for m in moved) else None
+        pmc_build = (pmc or {}).get("build_id")
         roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": (pmc or {}).get("provenance"),
+                    "traffic_build_id": pmc_build, "traffic_matches_build": (pmc_build == build_id) if pmc else None,
                     "algorithmic_bytes_per_launch": int(B), "avg_launch_ms": round(kernels_ms[dom], 4),
                     "valu": valu,
                     "whole_step": {"algorithmic_bytes": int(B_step), "GBps": round(B_step / (step_ms * 1e-3) / 1e9, 1),
                                    "frac_of_hbm_peak": round(B_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": "SURVEY.md 8(d) bytes of all kernels, priced as the table prices them -- the reference's "
-                                           "64-bit (tile | depth) key sort, p_s = ceil((32 + bit) / 8) passes over all "
-                                           "instances -- / this run's step time (this build moves fewer bytes: a 2-pass tile "
-                                           "partition of depth-ordered instances)"}}
+                                   "moved_bytes": moved,
+                                   "moved_frac_of_hbm_peak": (round(moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                              if moved else None),
+                                   "note": "algorithmic_bytes: SURVEY.md 8(d) bytes of all kernels, priced as the table prices "
+                                           "them (the reference's 64-bit (tile | depth) key sort, p_s = ceil((32 + bit) / 8) "
+                                           "passes over all instances) / this run's step time; moved_bytes: HBM bytes the "
+                                           "kernels of this build moved per step (PMC, the kernels in the traffic table). "
+                                           "north_star's 40 % of the HBM peak is not reachable while the two blend kernels "
+                                           "-- three quarters of the step -- are VALU-issue-bound"}}
 
     vif = None
-    if world == 1 and args.views_in_flight > 1 and len(dcams) > 1:
+    if world == 1 and not strong and args.views_in_flight > 1 and len(dcams) > 1:
         per_k, ref_digest = {}, None
         for nv in range(1, args.views_in_flight + 1):
             ms, gps, digest = run_views_in_flight(lib, _C, device, dev, dcams, P, W, H, D, Vs, Rs, nv,
@@ -473,36 +729,66 @@ def main():
             assert digest == ref_digest, "a view's results changed with its neighbours"
             per_k[str(nv)] = {"ms_per_view": round(ms, 4), "value": gps}
         vif = {"unit": "Gaussians/s", "by_views_in_flight": per_k, "forward": "presized (no host read-back)",
-                 "note": "NOT the headline: K independent views of one multi-view batch on K HIP streams (each with its own "
-                         "state, workspace and outputs; one host thread); every view's outputs and gradients are "
-                         "bit-identical whatever runs beside it.  The reference's loop is one view per optimiser step."}
+               "note": "NOT the headline: K independent views of one multi-view batch on K HIP streams (each with its own "
+                       "state, workspace and outputs; one host thread); every view's outputs and gradients are "
+                       "bit-identical whatever runs beside it.  The reference's loop is one view per optimiser step."}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
         cpu_baseline = run_cpu_baseline(scene, cams[0], P, W, H, D)
+        if args.workload == "s3":
+            # SURVEY.md 8(d) asks for the CPU restatement on S1 and S2: both whole, in the same run, next to the sample
+            # of the headline's own workload
+            others = {}
+            for wl in ("s1", "s2"):
+                sc2, cams2, _d, _dc, (P2, W2, H2, D2) = build_scene(wl, torch.device("cpu"))
+                b = _cpu_baseline_once(sc2, cams2[0], P2, W2, H2, D2, P2)
+                b.pop("seconds")
+                others[wl] = b
+            cpu_baseline["other_workloads"] = others
 
-    ms_per_step = elapsed / args.steps * 1e3
+    kernels_sum = sum(kernels_ms.values()) if kernels_ms else None
     out = {
         "metric": "rasterized Gaussians/s fwd+bwd @1600x1200" if args.workload == "s3"
         else f"rasterized Gaussians/s fwd+bwd @{W}x{H}",
-        "value": units / elapsed, "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        # per-step time = the MEDIAN of the K timed steps (each bracketed by HIP events);
+        # value = units of the K steps / (K x median)
+        "value": units / (args.steps * step_ms * 1e-3), "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {P} surfels (room box), {W}x{H}, SH degree {D}, "
-                               f"{len(dcams)} views, 1 view/GPU/step", "P": P, "width": W, "height": H,
-                   "sh_degree": D, "visible_per_view": round(units / args.steps / world),
-                   "instances_per_view": round(inst / args.steps / world),
-                   "forward": "presized (no host read-back)" if args.presized else "reference-shaped",
+        "config": {"workload": f"{args.workload}: {P} surfels (room box), {W}x{H}, SH degree {D}, {len(dcams)} views, "
+                               + (f"{STRONG_VIEWS} views per step over {world} GPU(s): {views_per_rank} per GPU, accumulated "
+                                  f"locally ({min(3, views_per_rank)} in flight)" if strong else "1 view/GPU/step"),
+                   "P": P, "width": W, "height": H,
+                   "sh_degree": D, "visible_per_view": round(units / args.steps / world / views_per_rank),
+                   "instances_per_view": round(inst / args.steps / world / views_per_rank),
+                   "views_per_step": world * views_per_rank,
+                   "forward": "presized (no host read-back)" if (args.presized or strong) else "reference-shaped",
                    "parallelism": f"view-dp{world}" + ((("+rccl" if backend == "nccl" else "+" + backend) +
-                                                                   ("-owner-reduce(all_to_all+all_gather)" if exchange == "owner"
-                                                                    else "-visible-rows-" + exchange)) if world > 1 else ""),
+                                                        ("-owner-reduce(all_to_all+all_gather)" if exchange == "owner"
+                                                         else "-visible-rows-" + exchange)) if world > 1 else ""),
                    "exchanged_rows_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows
                                                else None),
-                   # GPU time of the gradient exchange per step on rank 0 (statistics + radii MAX + owner-reduce), from the
+                   # GPU time of the gradient exchange per step on rank 0 (what follows the backward), from the
                    # instrumented pass; it is part of every timed step at N > 1
                    "exchange_ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None},
-        "gaussians_total_per_s": P * args.steps * world / elapsed,
-        "instances_per_s": inst / elapsed,
+        "build_id": build_id,
+        "timing": {"protocol": "K steps between barrier + synchronize; one HIP event behind every step; ms_per_step = "
+                               "median of the K steps (SURVEY.md 8(d)); mean_ms = host clock over the region / K",
+                   "median_ms": round(head["median_ms"], 4), "mean_ms": round(head["mean_ms"], 4),
+                   "max_ms": round(head["max_ms"], 4), "min_ms": round(head["min_ms"], 4),
+                   "per_step_ms": head["per_step_ms"],
+                   "value_from_mean": units / (args.steps * head["mean_ms"] * 1e-3),
+                   "disturbed": head["disturbed"], "disturbed_steps": head["disturbed_steps"],
+                   "attempts": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
+                                 if k != "per_step_ms" or a["disturbed"]} for a in attempts],
+                   "warmup_extra_steps": settle["extra_steps"], "warmup_settled": settle["settled"],
+                   "warmup_windows_ms_per_step": settle["windows_ms_per_step"],
+                   "device_allocations_in_timed_region": int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)),
+                   "vs_sustained": (round(step_ms / sustained["ms_per_step"], 4) if sustained else None),
+                   "vs_kernels_sum": (round(step_ms / kernels_sum, 4) if (kernels_sum and not strong and world == 1) else None)},
+        "gaussians_total_per_s": P * args.steps * world * views_per_rank / (args.steps * step_ms * 1e-3),
+        "instances_per_s": inst / (args.steps * step_ms * 1e-3),
         "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},
         # per-kernel durations come from a second pass over the same K steps with a HIP-event pair around every kernel
         # group on the launch stream; the events cost GPU time themselves, so that pass is not the headline
@@ -511,10 +797,12 @@ def main():
                            "clock_state": ("settled (behind the sustained pass)" if sustained else "as found")}
                           if elapsed_events is not None else None),
         "sustained": sustained,
+        "exchange": exchange_info,
         "views_in_flight": vif,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(out))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -525,6 +813,7 @@ def run_views_in_flight(lib, _C, device, dev, dcams, P, W, H, D, Vs, Rs, K, step
     Views of one multi-view batch (gradient accumulation; SURVEY.md 8(e)'s 8 views over fewer than 8 GPUs) are
     independent, so one view's launch-bound binning and HBM-bound per-Gaussian kernels run beside another view's
     VALU-bound blend kernels.  Returns (ms per view, Gaussians/s, digest of view 1's results)."""
+    import torch
     from g4splat_amd.pipeline import ViewPipeline
     bg = torch.zeros(3, device=device)
     empty = torch.empty(0, device=device)
@@ -567,6 +856,7 @@ def read_sclk_mhz(device_index=0):
     The box exposes the whole node's cards in sysfs: the one that belongs to the device is found by its PCI address."""
     import glob
     import re
+    import torch
     try:
         pr = torch.cuda.get_device_properties(device_index)
         bdf = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
@@ -587,8 +877,8 @@ def pmc_profile(workload):
     """The committed rocprofv3 PMC summary of this workload (profiles/r<NN>_traffic_<workload>.json, newest round
     first; written by tools/profile_gpu.sh + tools/summarize_prof.py on the GPU box): FETCH_SIZE / WRITE_SIZE in KiB
     (separate passes; HBM bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md),
-    SQ_INSTS_VALU and GRBM_GUI_ACTIVE per launch.  These counters cannot be collected inside this process, so the
-    bench line labels them with `provenance` (file + the commit the profiled library was built from)."""
+    SQ_INSTS_VALU and GRBM_GUI_ACTIVE per launch, and `build_id` = g4s_version()'s id of the library the counters were
+    collected on.  These counters cannot be collected inside this process, so the bench line labels them."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{workload}.json")), reverse=True)
     cands.append(os.path.join(ROOT, "profiles", f"traffic_{workload}.json"))
@@ -615,6 +905,7 @@ def run_cpu_baseline(scene, cam, P, W, H, D, target_gaussians=150_000, target_se
 def _cpu_baseline_once(scene, cam, P, W, H, D, target_gaussians):
     """CPU restatement of the reference algorithm (oracle/, 'port') on the host cores, bounded sample:
     a seeded subset of the same scene, same camera and resolution."""
+    import numpy as np
     from oracle import oracle as om
     om.build()
     n = min(P, target_gaussians)
@@ -633,9 +924,9 @@ def _cpu_baseline_once(scene, cam, P, W, H, D, target_gaussians):
     dt = time.perf_counter() - t0
     V = int((radii > 0).sum())
     return {"seconds": dt, "value": V / dt, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"workload of this line, bounded: {n} of {P} surfels (seeded subset), same view 0 at {W}x{H}, 1 fwd+bwd, "
-                      f"{V} visible, {R} instances, {dt:.2f} s, OpenMP over all host cores (oracle/surfel_oracle.c; "
-                      f"SURVEY.md 8(d) asks for S1/S2: run --workload s1 / s2 for those)"}
+            "sample": (f"{n} of {P} surfels" + (" (seeded subset)" if n < P else " (the whole scene)") +
+                       f", view 0 at {W}x{H}, 1 fwd+bwd, {V} visible, {R} instances, {dt:.2f} s, OpenMP over all host "
+                       f"cores (oracle/surfel_oracle.c)")}
 
 
 if __name__ == "__main__":

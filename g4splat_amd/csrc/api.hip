@@ -190,7 +190,11 @@ extern "C" int g4s_get_option(const char* name, int* value) {
         if (name && !strcmp(name, o.name)) { if (value) *value = o.value.load(std::memory_order_relaxed); return G4S_OK; }
     return fail(G4S_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
 }
-extern "C" const char* g4s_version(void) { return "g4s-hip 0.1.0 gfx950"; }
+#ifndef G4S_BUILD_ID
+#define G4S_BUILD_ID "unknown"
+#endif
+// "... build <id>": the id is the digest of the library's sources (csrc/Makefile)
+extern "C" const char* g4s_version(void) { return "g4s-hip 0.1.0 gfx950 build " G4S_BUILD_ID; }
 
 extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out) {
     if (!out || P < 0 || R < 0 || width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "bad layout query");

@@ -170,6 +170,8 @@ class OwnerReduce:
         with (torch.cuda.device(dev) if self.hip else _nullctx()):
             # ---- persistent state (LAB_NOTES.md: collectives on persistent buffers only)
             self._meta = torch.zeros(self.P + W2, dtype=torch.int32, device=dev)  # radii | count matrix [src, dst]
+            self._max_radii = torch.zeros(self.P, dtype=torch.int32, device=dev)  # what max_radii returns
+            self._ragged_stage = {}  # (dtype, width) -> (stage, mine): all_gather_rows with ragged shards
             self._idx = torch.empty(self.P, dtype=torch.int64, device=dev)
             self._edges = torch.tensor([min(d * self.shard, self.P) for d in range(self.world + 1)], dtype=torch.int64,
                                        device=dev)
@@ -188,24 +190,53 @@ class OwnerReduce:
         self._coalesce = self._probe_coalescing() if (self.rccl and not os.environ.get("G4S_OWNER_NO_COALESCE")) else False
         self.last_rows_sent = None
         self.allocations = 0  # buffer (re)allocations so far: stays constant once the exchange has warmed up
+        self.timing = False   # True (HIP devices): bracket the pieces of begin() / finish() with events -> read_timers()
+        self._timers = {}
+        self.last_bytes = {}  # bytes this rank sent / received in the last step's collectives, by piece
+
+    def _timed(self, name):
+        """Context manager: with `timing` on, a pair of HIP events on the current stream around the piece `name` (the
+        torch collectives are synchronous ops: the current stream waits for them, so the pair brackets the collective)."""
+        return _EventPair(self, name) if (self.timing and self.hip) else _nullctx()
+
+    def read_timers(self, reset=True):
+        """-> {piece: mean ms per step} of everything recorded since the last reset (synchronises on the events)."""
+        out = {}
+        for name, pairs in self._timers.items():
+            if pairs:
+                pairs[-1][1].synchronize()
+                out[name] = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        if reset:
+            self._timers = {}
+        return out
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     def _probe_coalescing(self):
+        """Can the per-tensor in-place all_gathers be issued as one RCCL group?  Decided in three steps so that no rank can
+        leave its peers inside a half-issued group: (1) every rank checks LOCALLY, without any collective, that this torch
+        has the coalescing manager and all_gather_into_tensor; (2) the flags are MIN-reduced -- the one collective every
+        rank issues whatever its flag; (3) only if all ranks said yes is the grouped form run once on dummy tensors, and a
+        failure there is fatal (it raises on the failing rank instead of silently desynchronising the sequence)."""
         ok = 1
         try:
-            from torch.distributed.distributed_c10d import _coalescing_manager
-            a = torch.zeros(self.world, device=self.dev)
-            b = torch.zeros(self.world, device=self.dev)
-            with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
-                dist.all_gather_into_tensor(a, a[self.rank:self.rank + 1], group=self.group)
-                dist.all_gather_into_tensor(b, b[self.rank:self.rank + 1], group=self.group)
-        except Exception as ex:  # this torch / backend cannot coalesce them
-            import warnings
-            warnings.warn(f"OwnerReduce: coalesced in-place all_gather unavailable ({ex}); one collective per tensor")
+            from torch.distributed.distributed_c10d import _coalescing_manager  # noqa: F401
+            if not hasattr(dist, "all_gather_into_tensor"):
+                ok = 0
+        except ImportError:
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=self.dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(int(flag.item()))
+        if not int(flag.item()):
+            import warnings
+            warnings.warn("OwnerReduce: coalesced in-place all_gather unavailable on some rank; one collective per tensor")
+            return False
+        from torch.distributed.distributed_c10d import _coalescing_manager
+        a = torch.zeros(self.world, device=self.dev)
+        b = torch.zeros(self.world, device=self.dev)
+        with _coalescing_manager(group=self.group, device=self.dev, async_ops=False):
+            dist.all_gather_into_tensor(a, a[self.rank:self.rank + 1], group=self.group)
+            dist.all_gather_into_tensor(b, b[self.rank:self.rank + 1], group=self.group)
+        return True
 
     def bounds(self, d=None):
         """[lo, hi): the rows owner `d` (default: this rank) holds."""
@@ -216,8 +247,10 @@ class OwnerReduce:
 
     @property
     def max_radii(self):
-        """int32 [P]: MAX over the ranks of the radii handed to begin() (valid after finish())."""
-        return self._meta[:self.P]
+        """int32 [P]: MAX over the ranks of the radii handed to the last begin().  A persistent buffer of its own, filled
+        by finish() and valid until the NEXT finish() overwrites it (begin() does not touch it); clone it to keep it
+        longer."""
+        return self._max_radii
 
     def _buffer(self, which, rows):
         buf = getattr(self, which)
@@ -233,7 +266,7 @@ class OwnerReduce:
     def begin(self, visible: torch.Tensor, radii: Optional[torch.Tensor] = None):
         """`visible`: bool[P], the rows this rank's views can have touched (radii > 0, OR-ed over its views);
         `radii`: optional integer [P] tensor whose MAX over the ranks is wanted (max_radii after finish())."""
-        with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
+        with (torch.cuda.device(self.dev) if self.hip else _nullctx()), self._timed("begin_local"):
             # fixed-size index list (padded with P, ascending => grouped by owner): the host does not wait for a count
             if self._nonzero_static:
                 try:
@@ -255,7 +288,10 @@ class OwnerReduce:
             tail = meta[self.P:].view(self.world, self.world)
             tail.zero_()
             tail[self.rank].copy_(pos[1:] - pos[:-1])
-            dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.group)  # radii MAX + the count matrix, one collective
+        with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
+            with self._timed("max_all_reduce"):
+                dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.group)  # radii MAX + the count matrix, one collective
+            self.last_bytes["max_all_reduce"] = int(meta.numel() * 4 * 2 * (self.world - 1) / max(self.world, 1))
             if self.hip:
                 self._counts_host.copy_(meta[self.P:], non_blocking=True)
                 self._event.record(torch.cuda.current_stream(self.dev))
@@ -287,8 +323,12 @@ class OwnerReduce:
             for t in tensors:  # ragged: padded staging buffer per tensor
                 w = t[0].numel() if t.ndim > 1 else 1
                 flat = t.view(self.P, w)
-                stage = torch.zeros(self.world * self.shard, w, dtype=t.dtype, device=t.device)
-                mine = torch.zeros(self.shard, w, dtype=t.dtype, device=t.device)
+                key = (t.dtype, w)
+                if key not in self._ragged_stage:  # persistent per (dtype, width): nothing is allocated per step
+                    self._ragged_stage[key] = (torch.zeros(self.world * self.shard, w, dtype=t.dtype, device=t.device),
+                                               torch.zeros(self.shard, w, dtype=t.dtype, device=t.device))
+                    self.allocations += 1
+                stage, mine = self._ragged_stage[key]
                 mine[:hi - lo] = flat[lo:hi]
                 dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self.group)
                 flat.copy_(stage[:self.P])
@@ -315,6 +355,7 @@ class OwnerReduce:
         self._pending = False
         if self._event is not None:
             self._event.synchronize()  # recorded a whole backward ago: returns at once
+        self._max_radii.copy_(self._meta[:self.P])  # (the next begin() reuses _meta)
         mat = self._counts_host.view(self.world, self.world).tolist()
         send = [int(x) for x in mat[self.rank]]
         recv = [int(mat[s][self.rank]) for s in range(self.world)]
@@ -333,10 +374,11 @@ class OwnerReduce:
             # pack my visible rows, [n, width + 1] row-major: the rows for owner d are one contiguous range, and the
             # last column carries the row index (int32 bits), so rows and indices travel in ONE all_to_all
             if self.hip:
-                if a:
-                    self._rows_kernel(self._idx[:a], a, out_rows[:a], 10)
-                if total - b:
-                    self._rows_kernel(self._idx[b:total], total - b, out_rows[a:], 10)
+                with self._timed("pack"):
+                    if a:
+                        self._rows_kernel(self._idx[:a], a, out_rows[:a], 10)
+                    if total - b:
+                        self._rows_kernel(self._idx[b:total], total - b, out_rows[a:], 10)
             else:
                 idx = torch.cat((self._idx[:a], self._idx[b:total]))
                 off = 0
@@ -344,40 +386,48 @@ class OwnerReduce:
                     out_rows[:, off:off + w] = r.index_select(0, idx)
                     off += w
                 out_rows[:, W] = idx.to(torch.int32).view(torch.float32)
-            dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
+            with self._timed("all_to_all"):
+                dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
+            self.last_bytes["all_to_all_sent"] = n * (W + 1) * 4
+            self.last_bytes["all_to_all_received"] = m * (W + 1) * 4
             # owner: my own contribution already sits in my slice; add the other ranks' rows to it, source by source (a
             # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
             o = 0
-            for s_ in range(self.world):
-                c = recv[s_]
-                if c:
-                    if self.hip:
-                        self._rows_kernel(None, c, in_rows[o:o + c], 15)
-                    else:
-                        ridx = in_rows[o:o + c, W].contiguous().view(torch.int32).to(torch.int64)
-                        off = 0
-                        for r, w in zip(self.rows, self.widths):
-                            r.index_add_(0, ridx, in_rows[o:o + c, off:off + w])
-                            off += w
-                o += c
+            with self._timed("accumulate"):
+                for s_ in range(self.world):
+                    c = recv[s_]
+                    if c:
+                        if self.hip:
+                            self._rows_kernel(None, c, in_rows[o:o + c], 15)
+                        else:
+                            ridx = in_rows[o:o + c, W].contiguous().view(torch.int32).to(torch.int64)
+                            off = 0
+                            for r, w in zip(self.rows, self.widths):
+                                r.index_add_(0, ridx, in_rows[o:o + c, off:off + w])
+                                off += w
+                    o += c
             if not gather:
                 return
             # every rank gets every reduced shard
             lo, hi = self.bounds()
+            self.last_bytes["all_gather_sent_per_peer"] = (hi - lo) * W * 4
+            self.last_bytes["all_gather_received"] = (self.P - (hi - lo)) * W * 4
             if self.even:
-                self.all_gather_rows(self.rows)
+                with self._timed("all_gather"):
+                    self.all_gather_rows(self.rows)
                 return
-            off = 0
-            for r, w in zip(self.rows, self.widths):
-                self._acc[:hi - lo, off:off + w] = r[lo:hi]
-                off += w
-            dist.all_gather_into_tensor(self._gather.view(-1), self._acc.view(-1), group=self.group)
-            full = self._gather[:self.P]
-            # (shards are padded to `shard` rows: rank d's rows sit at [d * shard, d * shard + (hi_d - lo_d)) = their global index)
-            off = 0
-            for r, w in zip(self.rows, self.widths):
-                r.copy_(full[:, off:off + w])
-                off += w
+            with self._timed("all_gather"):
+                off = 0
+                for r, w in zip(self.rows, self.widths):
+                    self._acc[:hi - lo, off:off + w] = r[lo:hi]
+                    off += w
+                dist.all_gather_into_tensor(self._gather.view(-1), self._acc.view(-1), group=self.group)
+                full = self._gather[:self.P]
+                # (shards are padded to `shard` rows: rank d's rows sit at [d * shard, d * shard + (hi_d - lo_d)) = their global index)
+                off = 0
+                for r, w in zip(self.rows, self.widths):
+                    r.copy_(full[:, off:off + w])
+                    off += w
 
 
 class _nullctx:
@@ -385,6 +435,21 @@ class _nullctx:
         return self
 
     def __exit__(self, *exc):
+        return False
+
+
+class _EventPair:
+    def __init__(self, owner, name):
+        self.owner, self.name = owner, name
+
+    def __enter__(self):
+        self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.a.record(torch.cuda.current_stream(self.owner.dev))
+        return self
+
+    def __exit__(self, *exc):
+        self.b.record(torch.cuda.current_stream(self.owner.dev))
+        self.owner._timers.setdefault(self.name, []).append((self.a, self.b))
         return False
 
 

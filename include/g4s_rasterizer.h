@@ -48,7 +48,8 @@ typedef char* (*g4s_resize_fn)(void* ctx, size_t nbytes);
 /* Message of the last error raised on the calling thread ("" if none). */
 const char* g4s_last_error(void);
 
-/* Version / build identification: "g4s-hip <semver> gfx950". */
+/* Version / build identification: "g4s-hip <semver> gfx950 build <id>"; <id> = first 12 hex digits of the SHA-256 of the
+ * library's sources (csrc/Makefile), so that profiles and bench lines can name the binary they were taken on. */
 const char* g4s_version(void);
 
 /*

@@ -104,28 +104,40 @@ def test_owner_reduce_device_path_with_two_ranks_on_one_gpu():
                 assert 0.3 * nvis < sent < 0.7 * nvis  # about half of a rank's visible rows belong to the other owner
 
 
-def test_bench_two_ranks_control_flow_on_one_gpu():
-    """bench.py's N > 1 path end to end (launcher, warm-up fallback logic, owner-reduce exchange inside the timed steps,
-    max-over-ranks timing, the one JSON line) with two gloo ranks sharing cuda:0 -- the bring-up mode bench.py documents
-    (G4S_BENCH_BACKEND / G4S_BENCH_ONE_DEVICE).  The numbers of such a run mean nothing; the control flow is what the
-    driver's multi-GPU run will execute."""
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
+    """`python bench.py --gpus 2` as ONE command (it starts its own ranks through torch.distributed.run): the N > 1 path
+    end to end (launcher, warm-up fallback logic, owner-reduce exchange inside the timed steps, max-over-ranks timing,
+    per-step events, the one JSON line) with two gloo ranks sharing cuda:0 -- the bring-up mode bench.py documents
+    (G4S_BENCH_BACKEND / G4S_BENCH_ONE_DEVICE) -- in both scaling forms: weak (one view per rank per step) and strong
+    (8 views per step, 4 per rank accumulated locally with views in flight).  The numbers of such a run
+    mean nothing; the control flow is what the driver's multi-GPU run will execute."""
     import json
     import subprocess
     root = os.path.dirname(HERE)
     env = dict(os.environ, G4S_BENCH_BACKEND="gloo", G4S_BENCH_ONE_DEVICE="1")
-    port = 36500 + (os.getpid() % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--workload", "s2", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "s2", "--no-cpu-baseline", "--scaling", scaling, "--sustained-seconds", "0.1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == scaling and d["value"] > 0
     assert "owner-reduce" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert d["config"]["views_per_step"] == (8 if scaling == "strong" else 2)
     assert d["config"]["exchanged_rows_per_step"] > 0
     assert d["config"]["exchange_ms_per_step"] > 0
+    ex = d["exchange"]
+    assert ex["rccl_ranks"] == 2 and ex["backend"] == "gloo" and ex["ran"].startswith("owner-reduce") and ex["why"] == "default"
+    assert set(ex["ms_pieces"]) >= {"begin_local", "max_all_reduce", "pack", "all_to_all", "accumulate", "all_gather"}
+    assert ex["bytes_per_rank"]["all_to_all_sent"] > 0 and ex["bytes_per_rank"]["all_gather_received"] > 0
+    t = d["timing"]
+    assert len(t["per_step_ms"]) == 3 and t["median_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    assert t["min_ms"] <= t["median_ms"] <= t["max_ms"] and isinstance(t["disturbed"], bool)
+    assert d["build_id"] and d["build_id"] != "unknown"
     assert d["cpu_baseline"] is None and d["roofline"] is not None
 
 

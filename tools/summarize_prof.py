@@ -52,7 +52,14 @@ if len(sys.argv) >= 4:
         kern["blend_bwd"] = {c: round(agg[hk][c] / max(cnt[hk][c], 1), 1)
                              for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE") if c in agg[hk]}
         kern["blend_bwd"]["kernel"] = hot
-    json.dump({"workload": sys.argv[3],
+    try:  # the id of the library the counters were just collected on (g4s_version(): digest of its sources)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from g4splat_amd import _lib
+        build_id = _lib.load().g4s_version().decode().split("build ")[-1]
+    except Exception as ex:  # noqa: BLE001
+        build_id = None
+        print("build id unavailable:", ex)
+    json.dump({"workload": sys.argv[3], "build_id": build_id,
                "provenance": (sys.argv[4] if len(sys.argv) >= 5 else "rocprofv3 --pmc passes (commit not recorded)") +
                              " -- static: collected by tools/profile_gpu.sh, not measured in the bench run that quotes it",
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, mean per dispatch, KiB "
