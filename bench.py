@@ -19,12 +19,14 @@ torch.distributed.run on 127.0.0.1); under torch.distributed.run it uses the ran
   --scaling strong  SURVEY.md 8(e)'s form: 8 views per optimiser step in total, 8/N per rank, accumulated
                     locally (views in flight on HIP streams, gradients summed in program order), then ONE exchange.
 
-Timing ("median of the steps after the warm-ups"): the K steps sit between barrier + synchronize on
-both sides and every step is bracketed by HIP events on the launch stream.  `ms_per_step` / `value` come from the
-MEDIAN step; `mean_ms` (host clock over the whole region / K), `max_ms` and `per_step_ms` are printed next to it, and
-when the mean exceeds the median by more than 10 % the pass is marked `disturbed` (with the steps that did it) and
-repeated, at most three times; every attempt is listed.  The warm-up is by state, not by count: after the W steps the
-driver asks for, stepping continues until three consecutive 10-step windows agree within 2 % (at most ~1 s).
+Timing: a pass is EXACTLY K steps between barrier + synchronize on both sides (host clock, MAX over the ranks), with one
+HIP event on the launch stream behind every step.  A pass whose mean step exceeds its median step by more than 10 % is
+`disturbed` (something other than the work landed in it; the steps that carry the excess are named).  Passes are
+repeated until three are undisturbed (at most --attempts); `ms_per_step` / `value` are those of the MEDIAN undisturbed pass
+-- the contract's quotient, units of the K steps / time of the K steps -- and `timing` lists every pass, the per-step
+durations and SURVEY.md 8(d)'s median step.  If no pass was clean the line says `"disturbed": true`.  The warm-up is by
+state, not by count: after the W steps the driver asks for, stepping continues until three consecutive windows of ~10 steps
+agree within 2 % (at most ~1 s).
 
 prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
 `roofline` for the dominant kernel and `cpu_baseline` (the CPU oracle timed on the host
@@ -71,7 +73,8 @@ def parse_args(argv=None):
                          "the warm-up, so that a full collection over the interpreter's ~10^6 long-lived objects cannot "
                          "land inside a timed pass; host-side hygiene, the GPU work is unchanged)")
     ap.add_argument("--no-settle", action="store_true", help="skip the state-based part of the warm-up")
-    ap.add_argument("--attempts", type=int, default=3, help="how often a disturbed headline pass is repeated")
+    ap.add_argument("--attempts", type=int, default=7,
+                    help="upper bound on the headline passes (K steps each; repeated until three are undisturbed)")
     ap.add_argument("--views-in-flight", type=int, default=3,
                     help="N = 1 only, reported next to the headline (never as `value`): throughput with up to this many "
                          "INDEPENDENT views in flight on separate HIP streams (multi-view batches; 0 / 1 = skip)")
@@ -501,16 +504,21 @@ def main():
             dt, per = float(tt[0].item()), [float(x) for x in tt[1:].tolist()]
         return dt, per
 
-    # ---- the headline: the contract's K steps; repeated (and said so) when something else landed in them -----------
+    # ---- the headline: the contract's K steps, as several passes -------------------------------------------------------
+    # Every pass is EXACTLY K steps between barrier + synchronize.  Passes are repeated until three of them are
+    # undisturbed (at most --attempts); the headline is the MEDIAN pass of the undisturbed ones (by its mean step time =
+    # host clock over the region / K, the contract's quotient) -- or, if no pass was clean, the median pass of all of
+    # them, and the line says `disturbed`.  Every pass is listed.
     attempts = []
     for _a in range(max(1, args.attempts)):
         elapsed, per_step = timed_steps(False)
         summ = summarize_steps(per_step, elapsed / args.steps * 1e3)
         summ["per_step_ms"] = [round(t, 4) for t in per_step]
         attempts.append(summ)
-        if not summ["disturbed"]:
+        if sum(1 for a in attempts if not a["disturbed"]) >= 3:
             break
-    head = attempts[-1]
+    clean = [a for a in attempts if not a["disturbed"]] or attempts
+    head = sorted(clean, key=lambda a: a["mean_ms"])[(len(clean) - 1) // 2]
     mem1 = torch.cuda.memory_stats(device)
 
     # Sustained throughput: the same step, issued back to back right behind the headline pass (no pause anywhere), for
@@ -632,7 +640,7 @@ def main():
                 kernels_ms[lib.g4s_profile_name(k).decode()] = ms.value / cnt.value
         lib.g4s_profile_reset()
 
-    step_ms = head["median_ms"]
+    step_ms = head["mean_ms"]
     # roofline of the dominant kernel (rank 0's view mix)
     roofline = None
     if kernels_ms:
@@ -751,8 +759,8 @@ def main():
     out = {
         "metric": "rasterized Gaussians/s fwd+bwd @1600x1200" if args.workload == "s3"
         else f"rasterized Gaussians/s fwd+bwd @{W}x{H}",
-        # per-step time = the MEDIAN of the K timed steps (each bracketed by HIP events);
-        # value = units of the K steps / (K x median)
+        # value = units of the K steps / the time of the K steps (barrier + synchronize on both sides, MAX over ranks) of
+        # the median pass (see `timing`)
         "value": units / (args.steps * step_ms * 1e-3), "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -763,6 +771,7 @@ def main():
                    "sh_degree": D, "visible_per_view": round(units / args.steps / world / views_per_rank),
                    "instances_per_view": round(inst / args.steps / world / views_per_rank),
                    "views_per_step": world * views_per_rank,
+                   "visible_by_view_rank0": {str(c): Vs[c] for c in sorted(Vs)},
                    "forward": "presized (no host read-back)" if (args.presized or strong) else "reference-shaped",
                    "parallelism": f"view-dp{world}" + ((("+rccl" if backend == "nccl" else "+" + backend) +
                                                         ("-owner-reduce(all_to_all+all_gather)" if exchange == "owner"
@@ -773,12 +782,16 @@ def main():
                    # instrumented pass; it is part of every timed step at N > 1
                    "exchange_ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None},
         "build_id": build_id,
-        "timing": {"protocol": "K steps between barrier + synchronize; one HIP event behind every step; ms_per_step = "
-                               "median of the K steps (SURVEY.md 8(d)); mean_ms = host clock over the region / K",
-                   "median_ms": round(head["median_ms"], 4), "mean_ms": round(head["mean_ms"], 4),
+        "timing": {"protocol": "passes of exactly K steps between barrier + synchronize (host clock, MAX over ranks), one HIP "
+                               "event behind every step; repeated until 3 passes are undisturbed (mean <= 1.1 x median step); "
+                               "ms_per_step = mean step time of the MEDIAN undisturbed pass; `median_ms` = SURVEY.md 8(d)'s "
+                               "median step of that pass (the steps cycle through views of different cost, so the median "
+                               "of the mix sits ~2 % above its mean)",
+                   "passes": len(attempts), "undisturbed_passes": sum(1 for a in attempts if not a["disturbed"]),
+                   "mean_ms": round(head["mean_ms"], 4), "median_ms": round(head["median_ms"], 4),
                    "max_ms": round(head["max_ms"], 4), "min_ms": round(head["min_ms"], 4),
                    "per_step_ms": head["per_step_ms"],
-                   "value_from_mean": units / (args.steps * head["mean_ms"] * 1e-3),
+                   "value_from_median_step": units / (args.steps * head["median_ms"] * 1e-3),
                    "disturbed": head["disturbed"], "disturbed_steps": head["disturbed_steps"],
                    "attempts": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
                                  if k != "per_step_ms" or a["disturbed"]} for a in attempts],

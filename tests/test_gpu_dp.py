@@ -73,8 +73,13 @@ def _worker(rank, world, port, q):
                 a_[vis] = vals[vis]; b_[vis] = vals[vis]
             ra.begin(vis, radii=radii); ra.finish(); full.step()
             rb.begin(vis, radii=radii); rb.finish(gather=False); sh.step()
+            if it == 0:
+                first = (ra.allocations, rb.allocations)
         torch.cuda.synchronize()
-        zero1.append((P, all(torch.equal(a_.detach(), b_) for a_, b_ in zip(pa, pb)), ra.allocations, rb.allocations))
+        # persistent buffers only: whatever the first step allocated (send / receive buffers, the per-width staging of
+        # ragged shards) may at most be regrown once by a larger visible set; nothing is allocated per step
+        zero1.append((P, all(torch.equal(a_.detach(), b_) for a_, b_ in zip(pa, pb)), ra.allocations - first[0],
+                      rb.allocations - first[1]))
     q.put((rank, out, zero1))
     dist.barrier()
     dist.destroy_process_group()
@@ -96,7 +101,7 @@ def test_owner_reduce_device_path_with_two_ranks_on_one_gpu():
     for r in (0, 1):
         for P, same_params, alloc_a, alloc_b in zero1[r]:
             assert same_params, (r, P, "owner-applied Adam differs from the replicated FusedAdam")
-            assert alloc_a <= 3 and alloc_b <= 3, (alloc_a, alloc_b)  # send + receive buffer, grown at most once
+            assert alloc_a <= 2 and alloc_b <= 2, (alloc_a, alloc_b)  # after step one: send / receive regrown at most once
         for P, frac, same, sent, nvis in res[r]:
             assert same, (r, P, frac)
             assert 0 <= sent <= nvis
@@ -135,7 +140,8 @@ def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
     assert set(ex["ms_pieces"]) >= {"begin_local", "max_all_reduce", "pack", "all_to_all", "accumulate", "all_gather"}
     assert ex["bytes_per_rank"]["all_to_all_sent"] > 0 and ex["bytes_per_rank"]["all_gather_received"] > 0
     t = d["timing"]
-    assert len(t["per_step_ms"]) == 3 and t["median_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    assert len(t["per_step_ms"]) == 3 and t["mean_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    assert 1 <= t["undisturbed_passes"] <= t["passes"] == len(t["attempts"])
     assert t["min_ms"] <= t["median_ms"] <= t["max_ms"] and isinstance(t["disturbed"], bool)
     assert d["build_id"] and d["build_id"] != "unknown"
     assert d["cpu_baseline"] is None and d["roofline"] is not None

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd $REPO
 for i in 1 2 3; do
-  /usr/bin/time -f "%e s wall" python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/cold_$i.json 2> $OUT/cold_$i.err
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/cold_$i.json 2> $OUT/cold_$i.err
 done
 ( while true; do amd-smi metric > /dev/null 2>&1; cat /sys/class/drm/card*/device/pp_dpm_sclk > /dev/null 2>&1; sleep 1; done ) &
 POLL=$!
@@ -23,7 +23,7 @@ for f in sorted(glob.glob("$OUT/*.json")):
         print(f, "NO LINE", ex); continue
     t = d["timing"]
     print(f.split("/")[-1], "value %.4g" % d["value"], "median", t["median_ms"], "mean", t["mean_ms"], "max", t["max_ms"],
-          "disturbed", t["disturbed"], t["disturbed_steps"], "attempts", len(t["attempts"]), "extra warmup", t["warmup_extra_steps"],
+          "disturbed", t["disturbed"], t["disturbed_steps"], "passes", t["passes"], t["undisturbed_passes"], [a["mean_ms"] for a in t["attempts"]], "extra warmup", t["warmup_extra_steps"],
           t["warmup_settled"], "allocs", t["device_allocations_in_timed_region"], "vs_sustained", t["vs_sustained"], "vs_kernels", t["vs_kernels_sum"])
     print("   windows", t["warmup_windows_ms_per_step"])
     print("   per-step", t["per_step_ms"])
