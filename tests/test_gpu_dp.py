@@ -147,7 +147,7 @@ def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
     assert d["cpu_baseline"] is None and d["roofline"] is not None
 
 
-def _rccl_worker(q):
+def _rccl_worker(q, P=30000):
     root = os.path.dirname(HERE)
     for p in (root, HERE):
         if p not in sys.path:
@@ -158,7 +158,7 @@ def _rccl_worker(q):
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from g4splat_amd.parallel import OwnerReduce, ShardedAdam
-    P, widths = 30000, (3, 48, 1, 2, 4, 2)
+    widths = (3, 48, 1, 2, 4, 2)
     g = torch.Generator().manual_seed(3)
     vis = (torch.rand(P, generator=g) < 0.3).to(dev)
     rows = [torch.zeros(P, w, device=dev) for w in widths]
@@ -168,9 +168,12 @@ def _rccl_worker(q):
     radii = (vis * 9).to(torch.int32)
     red = OwnerReduce(rows)
     assert red.rccl
-    for _ in range(3):  # persistent buffers: the same collectives on the same memory every step
+    dev_allocs = []
+    for _ in range(4):  # persistent buffers: the same collectives on the same memory every step
         red.begin(vis, radii=radii)
         red.finish()
+        torch.cuda.synchronize()
+        dev_allocs.append((torch.cuda.memory_stats(dev)["num_device_alloc"], red.allocations))
     params = [torch.randn(P, w, generator=g).to(dev) for w in widths[:5]]
     before = [p.clone() for p in params]
     opt = ShardedAdam(params, rows[:5], red, (1e-3,) * 5)
@@ -180,25 +183,29 @@ def _rccl_worker(q):
     torch.cuda.synchronize()
     q.put((all(torch.equal(a, b) for a, b in zip(rows, want)), bool(torch.equal(red.max_radii, radii)), red._coalesce,
            red.allocations, all(not torch.equal(a, b) for a, b in zip(params, before)),
-           all(bool(torch.isfinite(p).all()) for p in params)))
+           all(bool(torch.isfinite(p).all()) for p in params), dev_allocs))
     dist.destroy_process_group()
 
 
-def test_owner_reduce_and_sharded_adam_on_the_rccl_backend():
-    """Verdict r2 item 3d: the whole exchange on the **nccl** (= RCCL) backend, at the world size a one-GPU box allows:
-    the fused MAX collective, the uneven all_to_all (zero-row splits: every row is self-owned), the in-place all_gather
-    issued as one RCCL group, and the owner-applied Adam with its parameter gather are executed BY RCCL on the
-    persistent buffers, three steps in a row; results are the identity on one rank."""
+@pytest.mark.parametrize("P", [30000, 1_500_000])
+def test_owner_reduce_and_sharded_adam_on_the_rccl_backend(P):
+    """Verdict r2 item 3d / r3 item 3: the whole exchange on the **nccl** (= RCCL) backend, at the world size a one-GPU box
+    allows, at a small size and at S3's row count (1.5 M rows x 61 floats): the fused [P + 1] int32 MAX collective, the
+    uneven all_to_all (zero-row splits: every row is self-owned), the in-place all_gather issued as one RCCL group, and
+    the owner-applied Adam with its parameter gather are executed BY RCCL on the persistent buffers, four steps in a
+    row; results are the identity on one rank, and after the first step neither the exchange nor torch's allocator
+    obtains device memory (hipMalloc count constant)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p = ctx.Process(target=_rccl_worker, args=(q, P))
     p.start()
-    same, radii_ok, coalesced, allocs, stepped, finite = q.get(timeout=300)
+    same, radii_ok, coalesced, allocs, stepped, finite, dev_allocs = q.get(timeout=300)
     p.join(timeout=60)
     assert p.exitcode == 0
     assert same and radii_ok and stepped and finite
     assert allocs <= 2, allocs
     assert isinstance(coalesced, bool)
+    assert all(a == dev_allocs[1] for a in dev_allocs[1:]), dev_allocs  # nothing allocated after the warm-up step
 
 
 def test_views_in_flight_on_separate_streams_are_bit_identical(hip_lib):
