@@ -236,7 +236,7 @@ def main():
 
     pstate = None
     pipe = None
-    slot_buckets = None
+    slot_tmp = tmp_vis = None
     vis_union = torch.zeros((P,), dtype=torch.bool, device=device) if strong else None
 
     def views_of_step(i):
@@ -292,9 +292,9 @@ def main():
 
     def step_strong(i):
         """One optimiser step of SURVEY.md 8(e)'s form: this rank's 8/N views go through a ViewPipeline (presized forward,
-        up to three views in flight on HIP streams); every view's backward writes its slot's own gradient bucket, which
-        is added to the step's bucket in program order (the accumulating stream waits for the previous view's slot:
-        bit-identical to the sequential loop); the exchange's begin() is issued right after the LAST view's forward (the
+        up to three views in flight on HIP streams); the first view's backward writes the step's gradient bucket, the
+        following ones add their visible rows to it in program order (accumulating backward: only its per-Gaussian kernel
+        waits for the previous view, so the sums are bit-identical to the sequential loop's); the exchange's begin() is issued right after the LAST view's forward (the
         union of the views' visible sets is known then) so that its collective hides behind that view's backward."""
         nonlocal exchange_events
         vs = views_of_step(i)
@@ -303,7 +303,6 @@ def main():
         for j, c in enumerate(vs):
             cam = dcams[c]
             with pipe.slot(j) as (state, work):
-                sflat, sviews, sside = slot_buckets[j % pipe.k]
                 fw = _C.rasterize_gaussians_presized(state, bg, dev["means3D"], empty, dev["opacity"], dev["scales"],
                                                      dev["rotations"], 1.0, empty, cam["view"], cam["proj"],
                                                      cam["tanfovx"], cam["tanfovy"], H, W, dev["sh"], D, cam["campos"],
@@ -324,20 +323,28 @@ def main():
                         torch.maximum(rmax, r2, out=rmax)
                     if dist is not None and exchange == "owner":
                         reducer.begin(vis_union, radii=rmax)
-                out = dict(sviews)
+                # The first view of the step overwrites the step's bucket (every row written, dL_dsh cleared on the
+                # side); the following ones ADD their visible rows to it (g4s_rasterizer_backward_accumulate): the
+                # accumulating per-Gaussian kernel waits for the previous view's slot, the blend kernels do not.
+                out = dict(grad_out)
                 out["workspace"] = work
+                if j > 0:
+                    out["accumulate"] = True
+                    out["after"] = pipe.previous_view_done
                 grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
                                                         1.0, empty, cam["view"], cam["proj"], cam["tanfovx"],
                                                         cam["tanfovy"], dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"],
                                                         fw[4], fw[0], fw[5], fw[6], False, out=out)
-                # per-view densification statistics BEFORE any reduction (gaussian_model.py:649-651), into the slot's side
-                torch.linalg.vector_norm(grads[0][:, :2], dim=1, out=sside[:, 0])
-                sside[:, 1] = radii > 0
-                pipe.after_previous_view()  # the sums below happen view after view, in program order
+                # per-view densification statistics BEFORE any reduction (gaussian_model.py:649-651), summed view after view
+                tmp = slot_tmp[j % pipe.k]
+                torch.linalg.vector_norm(grads[0][:, :2], dim=1, out=tmp[:, 0])
+                torch.gt(radii, 0, out=tmp_vis[j % pipe.k])
+                tmp[:, 1] = tmp_vis[j % pipe.k]
+                pipe.after_previous_view()  # (the waits are satisfied already when j > 0: the backward has waited)
                 if j == 0:
-                    bucket.copy_(sflat)
+                    side.copy_(tmp)
                 else:
-                    bucket.add_(sflat)
+                    side.add_(tmp)
                 res.append((fw[0], radii))
         pipe.join()
         if dist is not None:
@@ -399,11 +406,8 @@ def main():
             del fw
         from g4splat_amd.pipeline import ViewPipeline
         pipe = ViewPipeline(P, W, H, int(max(Rs.values()) * 1.25) + 4096, device, k=min(3, views_per_rank))
-        slot_buckets = []
-        for _ in range(pipe.k):
-            sflat, sviews = make_bucket()
-            sside = sviews.pop("side")
-            slot_buckets.append((sflat, sviews, sside))
+        slot_tmp = [torch.zeros((P, 2), device=device) for _ in range(pipe.k)]
+        tmp_vis = [torch.zeros((P,), dtype=torch.bool, device=device) for _ in range(pipe.k)]
         torch.cuda.synchronize()
     if dist is not None and exchange == "owner":
         try:

@@ -502,7 +502,8 @@ static int rasterizer_backward_impl(
     float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
     float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
-    float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream_) {
+    float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream_, bool accumulate = false,
+    void* after_event = nullptr) {
     (void)scale_modifier;
     hipStream_t stream = (hipStream_t)stream_;
     t_err[0] = 0;
@@ -573,7 +574,8 @@ static int rasterizer_backward_impl(
         bb.hot_count = hot_count; bb.hot_list = hot_list;
         // dL_dsh is mostly zero rows (invisible Gaussians).  When the one-wave kernel runs, its workgroups clear the
         // tensor on the side (blend.hip) and K8 writes the visible rows only; otherwise K8 clears the rows it skips.
-        if (bb.hot_threshold >= 0 && M > 0 && !opt(OPT_NO_SIDE_ZERO)) {
+        // (accumulating: dL_dsh holds the sum over the previous views -- nothing is cleared anywhere)
+        if (bb.hot_threshold >= 0 && M > 0 && !opt(OPT_NO_SIDE_ZERO) && !accumulate) {
             float* zb[2] = {dL_dsh, dL_dsh_rest};
             const size_t zn[2] = {(size_t)P * (dL_dsh_rest ? 1 : M) * 3, dL_dsh_rest ? (size_t)P * (M - 1) * 3 : 0};
             bool ok = true;
@@ -603,6 +605,10 @@ static int rasterizer_backward_impl(
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
     pb.rec_flag = rec_flag; pb.n_slots = (uint32_t)R;
     pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest; pb.sh_prezeroed = sh_prezeroed;
+    pb.accumulate = accumulate;
+    // The blend backward above touches only this call's own state; the per-Gaussian kernel below adds into tensors that
+    // the previous view's backward -- on another stream -- may still be adding into: it waits for the caller's event.
+    if (after_event) HIP_TRY(hipStreamWaitEvent(stream, (hipEvent_t)after_event, 0));
     pb.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16) && !misaligned(dL_dsh, 16));
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dtransMat = dL_dtransMat; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale;
@@ -644,6 +650,26 @@ extern "C" int g4s_rasterizer_backward_split_sh(
                                     dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh_dc,
                                     M > 1 ? dL_dsh_rest : nullptr, dL_dscale, dL_drot, workspace, workspace_bytes, debug,
                                     stream);
+}
+
+// Gradient accumulation over views (include/g4s_rasterizer.h).  sh_rest == NULL: sh_dc is the packed [P,M,3] tensor.
+extern "C" int g4s_rasterizer_backward_accumulate(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+    const float* sh_dc, const float* sh_rest, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale,
+    float* dL_drot, char* workspace, size_t workspace_bytes, void* after_event, int debug, void* stream) {
+    t_err[0] = 0;
+    if (P > 0 && (!sh_dc || M < 1 || (sh_rest && M > 1 && !dL_dsh_rest)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "accumulating backward needs SH coefficients (packed, or sh_dc + sh_rest / dL_dsh_rest)");
+    return rasterizer_backward_impl(P, D, M, R, background, width, height, means3D, sh_dc, (sh_rest && M > 1) ? sh_rest : nullptr,
+                                    nullptr, scales, scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos,
+                                    tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths,
+                                    dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh_dc,
+                                    (sh_rest && M > 1) ? dL_dsh_rest : nullptr, dL_dscale, dL_drot, workspace, workspace_bytes,
+                                    debug, stream, true, after_event);
 }
 
 extern "C" int g4s_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix,

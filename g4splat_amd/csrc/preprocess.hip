@@ -485,6 +485,8 @@ __device__ __forceinline__ F3 dnormvdv(F3 v, F3 dv) {
 
 // backward.cu:20-139.  Writes all M coefficients of dL_dsh (zeros above the active degree)
 // and returns the view-direction term to add to dL_dmean.
+// ACC: the coefficients are ADDED to what dsh holds (gradient accumulation over views) and nothing is cleared.
+template <bool ACC>
 __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 pos, F3 campos, uint32_t clamp_bits,
                                           const float* dL_dcolor, float* __restrict__ dsh, float* __restrict__ dsh_rest,
                                           bool vec16) {
@@ -550,17 +552,18 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
         }
     }
     const int nact = (deg + 1) * (deg + 1);
+    auto put = [](float* p, float v) { if (ACC) *p += v; else *p = v; };
     if (dsh_rest != nullptr) {  // split layout: dsh = this Gaussian's [3], dsh_rest = its [M-1][3]
-        dsh[0] = coef[0] * dRGB[0]; dsh[1] = coef[0] * dRGB[1]; dsh[2] = coef[0] * dRGB[2];
+        put(dsh + 0, coef[0] * dRGB[0]); put(dsh + 1, coef[0] * dRGB[1]); put(dsh + 2, coef[0] * dRGB[2]);
 #pragma unroll
         for (int i = 1; i < 16; i++) {
-            if (i < M) {
+            if (i < M && (!ACC || i < nact)) {
                 const float cf = (i < nact) ? coef[i] : 0.0f;
-                dsh_rest[3 * (i - 1) + 0] = cf * dRGB[0]; dsh_rest[3 * (i - 1) + 1] = cf * dRGB[1];
-                dsh_rest[3 * (i - 1) + 2] = cf * dRGB[2];
+                put(dsh_rest + 3 * (i - 1) + 0, cf * dRGB[0]); put(dsh_rest + 3 * (i - 1) + 1, cf * dRGB[1]);
+                put(dsh_rest + 3 * (i - 1) + 2, cf * dRGB[2]);
             }
         }
-        for (int i = 45; i < (M - 1) * 3; i++) dsh_rest[i] = 0.0f;
+        if (!ACC) for (int i = 45; i < (M - 1) * 3; i++) dsh_rest[i] = 0.0f;
     } else if (vec16) {  // M == 16, 16-byte aligned 192-byte record: twelve 16-byte stores
         float o[48];
 #pragma unroll
@@ -569,17 +572,27 @@ __device__ __forceinline__ F3 sh_backward(int deg, int M, const float* sh, F3 po
             o[3 * i] = cf * dRGB[0]; o[3 * i + 1] = cf * dRGB[1]; o[3 * i + 2] = cf * dRGB[2];
         }
         float4* o4 = reinterpret_cast<float4*>(dsh);
+        if (ACC) {  // read-modify-write of the quads that hold active coefficients (all twelve loads first)
+            const int nq = (3 * nact + 3) >> 2;
+            float4 old[12];
 #pragma unroll
-        for (int q = 0; q < 12; q++) o4[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            for (int q = 0; q < 12; q++) if (q < nq) old[q] = o4[q];
+#pragma unroll
+            for (int q = 0; q < 12; q++)
+                if (q < nq) o4[q] = make_float4(old[q].x + o[4 * q], old[q].y + o[4 * q + 1], old[q].z + o[4 * q + 2], old[q].w + o[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 12; q++) o4[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            if (i < M) {
+            if (i < M && (!ACC || i < nact)) {
                 const float cf = (i < nact) ? coef[i] : 0.0f;
-                dsh[3 * i + 0] = cf * dRGB[0]; dsh[3 * i + 1] = cf * dRGB[1]; dsh[3 * i + 2] = cf * dRGB[2];
+                put(dsh + 3 * i + 0, cf * dRGB[0]); put(dsh + 3 * i + 1, cf * dRGB[1]); put(dsh + 3 * i + 2, cf * dRGB[2]);
             }
         }
-        for (int i = 48; i < M * 3; i++) dsh[i] = 0.0f;
+        if (!ACC) for (int i = 48; i < M * 3; i++) dsh[i] = 0.0f;
     }
     const F3 dL_ddir = mk3(dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
                            dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
@@ -804,7 +817,11 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
 // block stay in LDS -- the first design wrote them to HBM from a lean fold kernel and read them back here
 // (2 x 108 MB at S3 and a launch), to give the gather more resident waves; once the fold stopped being issue-bound
 // (16-lane rows) that round trip was the larger cost.
-template <int SH_MODE>
+// ACC (PreprocessBwdArgs::accumulate, gradient accumulation over views): the parameter gradients -- dL_dmean3D,
+// dL_dopacity, dL_dscale, dL_drot, dL_dsh -- are ADDED to what their tensors hold; blocks without a visible Gaussian
+// touch none of them and nothing is zero-filled.  The per-view outputs (dL_dmean2D, dL_dcolor, dL_dnormal,
+// dL_dtransMat) are written as always.
+template <int SH_MODE, bool ACC>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a, FoldShZero z0, FoldShZero z1) {
     // one LDS buffer, used twice: the folded terms (256 x 19 floats) of phase 1, then the block's 256 x 28 output floats
     // on their way to coalesced 16-byte stores (K8_OUT_* below)
@@ -934,7 +951,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         if (a.shs != nullptr) {
             float sh[48];
             load_sh(a.shs, SH_MODE == 2 ? a.shs_rest : nullptr, (size_t)idx, a.M, a.D, SH_MODE == 0, sh);
-            const F3 dm = sh_backward(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
+            const F3 dm = sh_backward<ACC>(a.D, a.M, sh, mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]),
                                       mk3(a.campos[0], a.campos[1], a.campos[2]), a.clamped[idx], g, dsh, dsh_rest, SH_MODE == 0);
             dmean3[0] += dm.x;
             dmean3[1] += dm.y;
@@ -950,7 +967,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     // Outputs: every thread parks its 28 floats in LDS, then the block writes each tensor's 256-row region with
     // coalesced 16-byte stores -- 7 store instructions per thread instead of 28 strided dword stores, three quarters of
     // which only carried the zeros of invisible Gaussians.
-    __syncthreads();  // every thread has taken its folded terms out of s_buf
+    // (the barrier: every thread has taken its folded terms out of s_buf)
+    const bool any_visible = __syncthreads_or(visible ? 1 : 0) != 0;
     {
         float* o = s_buf;
         o[K8_OUT_MEAN2D + 3 * t] = dmean2[0]; o[K8_OUT_MEAN2D + 3 * t + 1] = dmean2[1]; o[K8_OUT_MEAN2D + 3 * t + 2] = dmean2[2];
@@ -966,26 +984,34 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     __syncthreads();
     {
         const int rows = imin_(256, a.P - (int)blockIdx.x * 256);
-        auto flush = [&](float* base, int w, int lds_off) {
+        auto flush = [&](float* base, int w, int lds_off, bool acc) {
             if (base == nullptr) return;
+            if (acc && !any_visible) return;  // adding a block of zeros: leave the sums alone
             float* dst = base + (size_t)blockIdx.x * 256 * w;
             const float* src = s_buf + lds_off;
             const int n = rows * w;
             if ((((size_t)dst) & 15) == 0) {
-                for (int i = t; i < (n >> 2); i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
-                for (int i = (n & ~3) + t; i < n; i += 256) dst[i] = src[i];
+                for (int i = t; i < (n >> 2); i += 256) {
+                    float4 v = reinterpret_cast<const float4*>(src)[i];
+                    if (acc) {
+                        const float4 u = reinterpret_cast<const float4*>(dst)[i];
+                        v = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+                    }
+                    reinterpret_cast<float4*>(dst)[i] = v;
+                }
+                for (int i = (n & ~3) + t; i < n; i += 256) dst[i] = acc ? dst[i] + src[i] : src[i];
             } else {
-                for (int i = t; i < n; i += 256) dst[i] = src[i];
+                for (int i = t; i < n; i += 256) dst[i] = acc ? dst[i] + src[i] : src[i];
             }
         };
-        flush(a.dL_dmean2D, 3, K8_OUT_MEAN2D);
-        flush(a.dL_dnormal, 3, K8_OUT_NORMAL);
-        flush(a.dL_dopacity, 1, K8_OUT_OPACITY);
-        flush(a.dL_dcolor, 3, K8_OUT_COLOR);
-        flush(a.dL_dmean3D, 3, K8_OUT_MEAN3D);
-        flush(a.dL_dtransMat, 9, K8_OUT_TRANSMAT);
-        flush(a.dL_dscale, 2, K8_OUT_SCALE);
-        flush(a.dL_drot, 4, K8_OUT_ROT);
+        flush(a.dL_dmean2D, 3, K8_OUT_MEAN2D, false);
+        flush(a.dL_dnormal, 3, K8_OUT_NORMAL, false);
+        flush(a.dL_dopacity, 1, K8_OUT_OPACITY, ACC);
+        flush(a.dL_dcolor, 3, K8_OUT_COLOR, false);
+        flush(a.dL_dmean3D, 3, K8_OUT_MEAN3D, ACC);
+        flush(a.dL_dtransMat, 9, K8_OUT_TRANSMAT, false);
+        flush(a.dL_dscale, 2, K8_OUT_SCALE, ACC);
+        flush(a.dL_drot, 4, K8_OUT_ROT, ACC);
     }
 }
 
@@ -993,7 +1019,7 @@ void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     // dL_dsh rows of the Gaussians phase 2 does not write: cleared by the fold phase unless the blend backward did it
     FoldShZero z0{nullptr, 0}, z1{nullptr, 0};
-    if (a.M > 0 && a.dL_dsh != nullptr && !a.sh_prezeroed) {
+    if (a.M > 0 && a.dL_dsh != nullptr && !a.sh_prezeroed && !a.accumulate) {
         if (a.shs_rest != nullptr) {
             z0 = FoldShZero{a.dL_dsh, 3};
             if (a.M > 1) z1 = FoldShZero{a.dL_dsh_rest, (a.M - 1) * 3};
@@ -1002,9 +1028,15 @@ void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
         }
     }
     const dim3 grid((a.P + 255) / 256), block(256);
-    if (a.shs_rest != nullptr) hipLaunchKernelGGL(preprocess_bwd_kernel<2>, grid, block, 0, s, a, z0, z1);
-    else if (a.sh_vec16) hipLaunchKernelGGL(preprocess_bwd_kernel<0>, grid, block, 0, s, a, z0, z1);
-    else hipLaunchKernelGGL(preprocess_bwd_kernel<1>, grid, block, 0, s, a, z0, z1);
+    if (a.accumulate) {
+        if (a.shs_rest != nullptr) hipLaunchKernelGGL((preprocess_bwd_kernel<2, true>), grid, block, 0, s, a, z0, z1);
+        else if (a.sh_vec16) hipLaunchKernelGGL((preprocess_bwd_kernel<0, true>), grid, block, 0, s, a, z0, z1);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<1, true>), grid, block, 0, s, a, z0, z1);
+    } else {
+        if (a.shs_rest != nullptr) hipLaunchKernelGGL((preprocess_bwd_kernel<2, false>), grid, block, 0, s, a, z0, z1);
+        else if (a.sh_vec16) hipLaunchKernelGGL((preprocess_bwd_kernel<0, false>), grid, block, 0, s, a, z0, z1);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<1, false>), grid, block, 0, s, a, z0, z1);
+    }
 }
 
 }  // namespace g4s

@@ -226,6 +226,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     least g4s_rasterizer_backward_workspace(P, R) bytes to use instead of a fresh allocation (a training loop keeps
     one; nothing in it needs clearing).
 
+    `out["accumulate"] = True` (extension: g4s_rasterizer_backward_accumulate): the parameter gradients -- dL_dmeans3D,
+    dL_dopacity, dL_dsh (or dL_dsh_dc / dL_dsh_rest), dL_dscales, dL_drotations, all five REQUIRED in `out` -- are added
+    to what those tensors hold instead of overwriting them (rows of Gaussians this view does not see are not touched,
+    nothing is zero-filled): the second and later views of a multi-view batch.  `out["after"]`: a recorded
+    torch.cuda.Event -- the stream waits for it between the blend backward and the accumulating per-Gaussian kernel
+    (views in flight on several streams: pipeline.ViewPipeline hands out the previous view's event).
+
     The backward reads AND updates the forward's state chunks (the validity bytes of its gradient records live in the
     binning chunk): run at most one backward at a time per forward state, and with a PresizedState -- whose chunks
     are shared from frame to frame -- run the backward of a frame before the next forward into the same state."""
@@ -253,6 +260,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         fopt = dict(dtype=torch.float32, device=dev)
         alloc = torch.zeros if P == 0 else torch.empty  # the library writes every element when P > 0
         given = dict(out) if out else {}
+        accumulate = bool(given.pop("accumulate", False))
+        after = given.pop("after", None)
+        if accumulate:
+            need = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations"] + (["dL_dsh_dc", "dL_dsh_rest"] if split else ["dL_dsh"])
+            missing = [n for n in need if n not in given]
+            if missing:
+                raise RuntimeError(f"out['accumulate'] needs the running sums in out=: missing {missing}")
+            if colors is not None and colors.numel():
+                raise RuntimeError("out['accumulate']: colours must come from SH")
+        elif after is not None:
+            raise RuntimeError("out['after'] only applies to an accumulating backward")
 
         def make(shape, name=None, align=4, **kw):
             t = given.pop(name, None)
@@ -262,7 +280,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     or not t.is_contiguous() or (t.numel() and t.data_ptr() % align)):
                 raise RuntimeError(f"out['{name}'] must be a contiguous float32 {tuple(shape)} tensor on {dev}, "
                                    f"{align}-byte aligned")
-            if P == 0:
+            if P == 0 and not accumulate:
                 t.zero_()
             return t
 
@@ -301,7 +319,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             gc, go = _f32c(dL_dout_color), _f32c(dL_dout_others)
             rad = radii.contiguous()
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            if split:
+            if accumulate:
+                dc, rest = (_f32c(sh_dc), _f32c(sh_rest)) if split else (_f32c(sh, 16), None)
+                gdc, grest = (dL_dsh[0], dL_dsh[1]) if split else (dL_dsh, None)
+                ev = ctypes.c_void_p(after.cuda_event if after is not None else 0)
+                rc = lib.g4s_rasterizer_backward_accumulate(
+                    P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(dc), _ptr(rest), _ptr(sc),
+                    float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx),
+                    float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
+                    _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
+                    _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(gdc), _ptr(grest), _ptr(dL_dscales),
+                    _ptr(dL_drotations), _ptr(workspace), ws_bytes, ev, int(bool(debug)), stream)
+            elif split:
                 dc, rest = _f32c(sh_dc), _f32c(sh_rest)
                 rc = lib.g4s_rasterizer_backward_split_sh(
                     P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(dc), _ptr(rest), _ptr(sc),

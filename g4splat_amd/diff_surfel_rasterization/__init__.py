@@ -20,9 +20,18 @@ from torch import nn
 
 from . import _C
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "presized"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "presized", "last_num_rendered"]
 
 _slot = threading.local()
+
+# num_rendered of the most recent reference-shaped forward on this thread (what the reference's forward returns and
+# throws away, __init__.py:98): parallel.ViewParallel.accumulate sizes its PresizedStates from it.
+_last = threading.local()
+
+
+def last_num_rendered():
+    """Instance count of this thread's most recent forward that read it back (None before the first one / inside slots)."""
+    return getattr(_last, "value", None)
 
 
 @contextlib.contextmanager
@@ -46,7 +55,9 @@ def _forward(*fwd_args):
     The backward context is (workspace, state, the state's generation after this forward)."""
     slot = getattr(_slot, "value", None)
     if slot is None:
-        return _C.rasterize_gaussians(*fwd_args), None
+        out = _C.rasterize_gaussians(*fwd_args)
+        _last.value = int(out[0])
+        return out, None
     state = slot[0]
     out = _C.rasterize_gaussians_presized(state, *fwd_args)
     state.generation = getattr(state, "generation", 0) + 1

@@ -557,9 +557,11 @@ class ViewParallel:
         stats = vp.all_reduce()                           # ONE sum over xGMI + the small side channel
         optimizer.step(); vp.zero()
 
-    A rank that holds several views of the batch (8 views over 1 / 2 / 4 GPUs) can keep two of them in flight: put the body
-    of the loop in `with pipe.slot(j):` of a pipeline.ViewPipeline (after `pipe.order_accumulation(params)`, with
-    `pipe.after_previous_view()` in front of `record_view`) and `pipe.join()` before `all_reduce()`.
+    A rank that holds several views of the batch (8 views over 1 / 2 / 4 GPUs) hands the loop to `accumulate()`, which keeps
+    two of them in flight on HIP streams by default (pipeline.ViewPipeline; accumulation ordered, results bit-identical
+    to the loop above):
+
+        vp.accumulate(shard_views(batch, rank, world), view_step)   # view_step(view): render, loss, backward -> render()'s dict
     """
 
     def __init__(self, params: Iterable[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
@@ -574,6 +576,8 @@ class ViewParallel:
         self._visible = None
         self.compact_below = compact_below  # RowSparseAllReduce threshold; 0.0 = always dense
         self._reducer = self._side = None
+        self._pipe = self._pipe_key = None  # accumulate(): the ViewPipeline of the current (P, image size)
+        self._capacity = {}
         self.bucket = GradientBucket(params)
         n = self.bucket.params[0].shape[0]
         dev = self.bucket.flat.device
@@ -587,11 +591,81 @@ class ViewParallel:
 
     def record_view(self, viewspace_points, visibility_filter, radii):
         """Per-view densification statistics, taken before any reduction."""
+        # (no boolean-mask indexing: `x[mask] += ...` reads the count back and would stall a pipelined loop.  The same
+        # sums element by element: rows outside the filter get + 0.)
         g = viewspace_points.grad
-        self.grad_norm_sum[visibility_filter] += torch.norm(g[visibility_filter], dim=-1, keepdim=True)
-        self.vis_count[visibility_filter] += 1
-        self.max_radii = torch.maximum(self.max_radii, radii.to(self.max_radii.dtype))
-        self._visible = visibility_filter.clone() if self._visible is None else (self._visible | visibility_filter)
+        vis = visibility_filter.unsqueeze(1)
+        self.grad_norm_sum.add_(torch.where(vis, torch.norm(g, dim=-1, keepdim=True), torch.zeros_like(self.grad_norm_sum)))
+        self.vis_count.add_(vis.to(self.vis_count.dtype))
+        torch.maximum(self.max_radii, radii.to(self.max_radii.dtype), out=self.max_radii)
+        if self._visible is None:
+            self._visible = visibility_filter.clone()
+        else:
+            self._visible.logical_or_(visibility_filter)
+
+    def accumulate(self, views, view_step, in_flight: int = 2, instance_capacity: Optional[int] = None,
+                   check_overflow: bool = True):
+        """This rank's views of one optimisation step, accumulated locally (8 views over N < 8 GPUs).
+
+            vp.accumulate(shard_views(batch, rank, world), view_step)     # then vp.all_reduce(); optimizer.step(); vp.zero()
+
+        `view_step(view)` renders the view, forms its loss, calls `.backward()` and returns render()'s dict (this method
+        records the view's densification statistics from it).  With more than one view on a HIP device the views go
+        through a `pipeline.ViewPipeline` BY DEFAULT: `in_flight` of them on their own HIP streams (one view's
+        launch-bound binning and HBM-bound per-Gaussian kernels beside another's VALU-bound blend kernels), the
+        accumulation into `.grad` -- views of this object's bucket, persistent -- and the statistics ordered view after
+        view, so that parameters after any number of steps equal the sequential loop's bit for bit
+        (tests/test_gpu_dp.py).  `in_flight=1` is the plain sequential loop.
+
+        The pipeline's PresizedStates need a bound on the (Gaussian, tile) instances of a view: `instance_capacity`,
+        or -- by default -- 1.5 x the largest count seen in the first step at this (P, image size), which therefore runs
+        sequentially through the reference-shaped forward.  A view that exceeds the capacity is invalid:
+        `check_overflow` (one read of the device status words per step) raises."""
+        views = list(views)
+        params = self.bucket.params
+        dev = params[0].device
+
+        def plain():
+            from . import diff_surfel_rasterization as dsr
+            cap = 0
+            for v in views:
+                out = view_step(v)
+                self.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
+                cap = max(cap, dsr.last_num_rendered() or 0)
+            return cap
+
+        sizes = {(int(v.image_width), int(v.image_height)) for v in views}
+        if len(views) <= 1 or in_flight <= 1 or dev.type != "cuda" or len(sizes) != 1:
+            plain()
+            return
+        from .pipeline import ViewPipeline
+        (W, H), = sizes
+        key = (int(params[0].shape[0]), W, H, min(int(in_flight), len(views)))
+        if self._pipe_key != key:
+            if self._pipe is not None:
+                self._pipe.release_hooks()
+                self._pipe = None
+            cap = instance_capacity if instance_capacity is not None else self._capacity.get(key[:3])
+            if cap is None:  # first step at this size: learn the instance counts, view after view
+                self._capacity[key[:3]] = int(plain() * 1.5) + 4096
+                return
+            self._pipe = ViewPipeline(key[0], W, H, int(cap), dev, k=key[3])
+            self._pipe.order_accumulation(params)
+            self._pipe_key = key
+            try:  # the accumulation happens on the slots' streams on purpose (ordered by the hooks)
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            except AttributeError:
+                pass
+        pipe = self._pipe
+        for j, v in enumerate(views):
+            with pipe.slot(j):
+                out = view_step(v)
+                pipe.after_previous_view()
+                self.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
+        pipe.join()
+        if check_overflow and pipe.overflowed():
+            raise RuntimeError("ViewParallel.accumulate: a view binned more instances than the pipeline's capacity "
+                               f"({pipe.states[0].capacity}); pass a larger instance_capacity")
 
     def all_reduce(self):
         """Sum the gradient bucket (and the statistics) over all ranks.  Returns the reduced statistics."""

@@ -32,8 +32,9 @@ on every leaf that makes the accumulating stream wait for the previous view's sl
 exits; by then that view's backward has been issued), so the accumulations happen one after the other in program order and
 the sums are bit-identical to the sequential loop's.  `after_previous_view()` is the same wait for user code (densification
 statistics, running means).  The waits sit at the very end of a view's backward: nothing of the overlap is lost.
-(Keep the leaves' .grad buffers persistent -- zero_grad(set_to_none=False) -- so that no gradient tensor moves from one
-stream's allocator pool to another stream's reader; a view's backward must be issued before its slot is used again -- the
+(The leaves' .grad buffers must be persistent -- `order_accumulation` allocates missing ones on the caller's stream and
+`slot()` refuses to start a view when one has been dropped (zero_grad(set_to_none=True)): a gradient born inside a slot
+would move from that stream's allocator pool to the optimiser reading it on another stream; a view's backward must be issued before its slot is used again -- the
 autograd node checks that and raises otherwise.  Anything else produced inside a slot and read on another stream after
 join(), an image kept for logging say, follows torch's rule for cross-stream use: `t.record_stream(reader_stream)`.)
 
@@ -61,6 +62,7 @@ class ViewPipeline:
         self._done = [torch.cuda.Event() for _ in range(self.k)]  # recorded when a slot exits
         self._last_done = None
         self._hooks = []
+        self._ordered = []  # the leaves of order_accumulation: their .grad buffers must stay persistent
         for s in self.streams:
             with torch.cuda.stream(s):
                 self.states.append(_C.PresizedState(P, width, height, instance_capacity, self.device))
@@ -73,6 +75,14 @@ class ViewPipeline:
         and yields that slot's (PresizedState, backward workspace)."""
         j = i % self.k
         s = self.streams[j]
+        for p in self._ordered:
+            if p.grad is None:
+                # a .grad created inside a slot would come from the slot stream's allocator pool and be read by the
+                # optimiser on the caller's stream: freed back to that pool by zero_grad(set_to_none=True), it could be
+                # handed out again while the optimiser is still reading it
+                raise RuntimeError("ViewPipeline: a parameter registered with order_accumulation() has no .grad buffer "
+                                   "(zero_grad(set_to_none=True)?): keep the gradients persistent -- "
+                                   "optimizer.zero_grad(set_to_none=False) or GradientBucket.zero()")
         s.wait_stream(torch.cuda.current_stream(self.device))
         from .diff_surfel_rasterization import presized
         with torch.cuda.stream(s), presized(self.states[j], self.workspaces[j]):
@@ -81,6 +91,13 @@ class ViewPipeline:
             finally:
                 self._done[j].record(s)
                 self._last_done = self._done[j]
+
+    @property
+    def previous_view_done(self):
+        """The event recorded when the most recently exited slot was left (None before the first one): what
+        `out["after"]` of an accumulating `rasterize_gaussians_backward` takes -- the accumulating kernel of this view then
+        waits for the previous view's, and nothing else of this view does."""
+        return self._last_done
 
     def after_previous_view(self):
         """The current stream waits until everything issued inside the most recently exited slot has finished.  Call it
@@ -95,14 +112,20 @@ class ViewPipeline:
         def hook(grad):
             self.after_previous_view()
             return grad
+        params = list(params)
+        for p in params:
+            if p.grad is None:  # persistent buffers from the caller's stream, so that no gradient is born in a slot's pool
+                p.grad = torch.zeros_like(p)
         handles = [p.register_hook(hook) for p in params]
         self._hooks.extend(handles)
+        self._ordered.extend(params)
         return handles
 
     def release_hooks(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._ordered = []
 
     def join(self):
         """The caller's current stream waits for every slot's stream."""

@@ -239,6 +239,100 @@ def test_views_in_flight_on_separate_streams_are_bit_identical(hip_lib):
     assert all(r > 0 for r in rates)
 
 
+@pytest.mark.parametrize("split_sh", [False, True])
+def test_accumulating_backward_equals_the_sequential_sum_bit_for_bit(hip_lib, split_sh):
+    """g4s_rasterizer_backward_accumulate (several views per GPU per step, accumulated locally): the first
+    view's backward writes the running sums, the following views ADD to them.  Against separate backwards summed by torch
+    in the same order -- (g0 + g1) + g2 + ... -- every parameter gradient is BIT-identical, rows no view sees stay exactly
+    zero, the per-view outputs (dL_dmeans2D) are those of the separate call; and the same with the views in flight on
+    three HIP streams, only the accumulating kernel ordered by the previous view's event (`out["after"]`)."""
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from g4splat_amd.diff_surfel_rasterization import _C
+    from g4splat_amd.pipeline import ViewPipeline
+    device = torch.device("cuda", 0)
+    scene, cams, dev, dcams, (P, W, H, D) = bench.build_scene("s2", device)
+    dcams = dcams[:5]
+    bg = torch.zeros(3, device=device)
+    empty = torch.empty(0, device=device)
+    g = torch.Generator(device=device).manual_seed(1)
+    gc_ = torch.randn((3, H, W), device=device, generator=g)
+    go_ = torch.randn((7, H, W), device=device, generator=g)
+    sh = (dev["sh"][:, :1].contiguous(), dev["sh"][:, 1:].contiguous()) if split_sh else dev["sh"]
+    names = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations"] + (["dL_dsh_dc", "dL_dsh_rest"] if split_sh else ["dL_dsh"])
+
+    def pick(gr):  # the returned tuple -> {name: tensor} of the parameter gradients
+        d = {"dL_dmeans3D": gr[3], "dL_dopacity": gr[2], "dL_dscales": gr[6], "dL_drotations": gr[7]}
+        if split_sh:
+            d["dL_dsh_dc"], d["dL_dsh_rest"] = gr[5]
+        else:
+            d["dL_dsh"] = gr[5]
+        return d
+
+    def fwd(c, state=None):
+        a = (bg, dev["means3D"], empty, dev["opacity"], dev["scales"], dev["rotations"], 1.0, empty, c["view"], c["proj"],
+             c["tanfovx"], c["tanfovy"], H, W, sh, D, c["campos"], False, False)
+        return _C.rasterize_gaussians_presized(state, *a) if state is not None else _C.rasterize_gaussians(*a)
+
+    def bwd(c, fw, out=None):
+        return _C.rasterize_gaussians_backward(bg, dev["means3D"], fw[3], empty, dev["scales"], dev["rotations"], 1.0, empty,
+                                               c["view"], c["proj"], c["tanfovx"], c["tanfovy"], gc_, go_, sh, D, c["campos"],
+                                               fw[4], fw[0], fw[5], fw[6], False, out=out)
+
+    # separate backwards, summed by torch in view order
+    want, mean2d, seen, Rmax = None, [], torch.zeros(P, dtype=torch.bool, device=device), 0
+    for c in dcams:
+        fw = fwd(c)
+        Rmax = max(Rmax, int(fw[0]))
+        gr = bwd(c, fw)
+        seen |= fw[3] > 0
+        mean2d.append(gr[0].clone())
+        d = pick(gr)
+        want = {k: v.clone() for k, v in d.items()} if want is None else {k: want[k] + d[k] for k in want}
+    assert 0 < int(seen.sum()) < P
+
+    # (a) one stream: first view overwrites, the others accumulate
+    sums = {k: torch.full_like(v, float("nan")) for k, v in want.items()}  # (the first view must overwrite every element)
+    for j, c in enumerate(dcams):
+        fw = fwd(c)
+        out = dict(sums)
+        if j:
+            out["accumulate"] = True
+        gr = bwd(c, fw, out=out)
+        assert torch.equal(gr[0], mean2d[j])
+    for k in names:
+        assert torch.equal(sums[k], want[k]), k
+        assert not bool(sums[k][~seen].any()), k
+
+    # (b) three views in flight; only the accumulating kernel waits for the previous view
+    pipe = ViewPipeline(P, W, H, int(Rmax * 1.25) + 4096, device, k=3)
+    for rep in range(2):
+        sums2 = {k: torch.full_like(v, float("nan")) for k, v in want.items()}
+        for j, c in enumerate(dcams):
+            with pipe.slot(j) as (state, work):
+                fw = fwd(c, state)
+                out = dict(sums2)
+                out["workspace"] = work
+                if j:
+                    out["accumulate"] = True
+                    out["after"] = pipe.previous_view_done
+                gr = bwd(c, fw, out=out)
+        pipe.join()
+        torch.cuda.synchronize()
+        assert not pipe.overflowed()
+        for k in names:
+            assert torch.equal(sums2[k], want[k]), (rep, k)
+
+    # refusals: the running sums must be handed in, and `after` belongs to an accumulating call
+    fw = fwd(dcams[0])
+    with pytest.raises(RuntimeError, match="running sums"):
+        bwd(dcams[0], fw, out={"accumulate": True})
+    with pytest.raises(RuntimeError, match="only applies"):
+        bwd(dcams[0], fw, out={"after": torch.cuda.Event()})
+
+
 def test_multi_view_batch_through_render_and_autograd_on_two_streams():
     """A multi-view batch (8 views over fewer than 8 GPUs, accumulated locally) through the reference's
     own call sequence -- gaussian_renderer.render(), a loss, loss.backward() -- with each view inside a ViewPipeline slot:
@@ -323,6 +417,80 @@ def test_multi_view_batch_through_render_and_autograd_on_two_streams():
     pipe.release_hooks()
     # and the slot really was used: the second run's forward states are the pipeline's
     assert lib is not None and all(int(st.status[1].item()) > 0 for st in pipe.states)
+
+
+def test_view_parallel_accumulate_pipelines_by_default_and_matches_the_sequential_loop():
+    """Verdict r3 item 4: ViewParallel.accumulate() puts a rank's views of a step through a ViewPipeline by default (two in
+    flight, accumulation ordered).  20 optimiser steps (FusedAdam) of 4 views each, through the reference's call
+    sequence (render() -> loss -> backward()): parameters, Adam moments and densification statistics equal those of the
+    plain sequential loop (in_flight=1) BIT FOR BIT; the pipeline really ran (its states hold frames), the first step at a
+    size runs sequentially to learn the instance capacity, and a dropped .grad buffer is refused."""
+    from types import SimpleNamespace
+    import numpy as np
+    from g4splat_amd import synthetic
+    from g4splat_amd.gaussian_model import GaussianModel
+    from g4splat_amd.gaussian_renderer import render
+    from g4splat_amd.parallel import ViewParallel
+    dev = torch.device("cuda", 0)
+    P, W, H = 100_000, 640, 400
+    scene = synthetic.scene_room(P, seed=4)
+    cams = []
+    for c in synthetic.room_cameras(4, W, H, fovx_deg=90.0):
+        cams.append(SimpleNamespace(image_width=W, image_height=H, FoVx=c.FoVx, FoVy=c.FoVy,
+                                    world_view_transform=torch.tensor(c.world_view_transform, device=dev),
+                                    full_proj_transform=torch.tensor(c.full_proj_transform, device=dev),
+                                    camera_center=torch.tensor(c.camera_center, device=dev), znear=0.01, zfar=100.0))
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)
+    cfg = SimpleNamespace(depth_ratio=0.0, compute_cov3D_python=False)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    target = [torch.rand((3, H, W), device=dev, generator=g) for _ in cams]
+
+    def train(in_flight):
+        model = GaussianModel(sh_degree=3)
+        model.create_from_parameters(t(scene.means3D), t(scene.scales), t(scene.rotations),
+                                     t(np.clip(scene.shs[:, 0, :] * 0.28209479177387814 + 0.5, 0, 1).astype(np.float32)))
+        model.active_sh_degree = 3
+        model.training_setup()
+        vp = ViewParallel(model.parameters())
+        idx = {id(c): i for i, c in enumerate(cams)}
+
+        def view_step(cam):
+            out = render(cam, model, cfg, bg)
+            loss = (out["render"] - target[idx[id(cam)]]).abs().mean() + 0.05 * out["rend_dist"].mean() \
+                + 0.01 * (1 - out["rend_alpha"]).mean()
+            loss.backward()
+            return out
+
+        for it in range(20):
+            vp.accumulate(cams, view_step, in_flight=in_flight)
+            stats = vp.all_reduce()
+            model.optimizer.step()
+            if it == 19:
+                keep = {k: v.clone() for k, v in stats.items()}
+            vp.zero()
+        torch.cuda.synchronize()
+        state = [model.optimizer.state[p] for p in model.parameters()]
+        return ([p.detach().clone() for p in model.parameters()],
+                [st[k].clone() for st in state for k in ("exp_avg", "exp_avg_sq")], keep, vp, model
+
+    pa, ma, sa, vpa, _ = train(1)
+    pb, mb, sb, vpb, model_b = train(2)
+    assert vpa._pipe is None
+    assert vpb._pipe is not None and vpb._pipe.k == 2 and all(int(st.status[1].item()) > 0 for st in vpb._pipe.states)
+    for name, a, b in zip(("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"), pa, pb):
+        assert torch.equal(a, b), (name, (a - b).abs().max().item())
+    for a, b in zip(ma, mb):
+        assert torch.equal(a, b)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert float(sa["vis_count"].max()) == 4.0 and float(sa["grad_norm_sum"].max()) > 0
+    # a dropped gradient buffer is refused before a view is issued
+    model_b.optimizer.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="no .grad buffer"):
+        vpb.accumulate(cams, lambda cam: None, in_flight=2)
+    vpb.zero()  # re-attaches the bucket views
+    vpb._pipe.release_hooks()
 
 
 def test_backward_refuses_a_presized_state_that_rendered_another_view_since():
