@@ -236,7 +236,6 @@ def main():
 
     pstate = None
     pipe = None
-    slot_tmp = tmp_vis = None
     vis_union = torch.zeros((P,), dtype=torch.bool, device=device) if strong else None
 
     def views_of_step(i):
@@ -323,28 +322,21 @@ def main():
                         torch.maximum(rmax, r2, out=rmax)
                     if dist is not None and exchange == "owner":
                         reducer.begin(vis_union, radii=rmax)
-                # The first view of the step overwrites the step's bucket (every row written, dL_dsh cleared on the
-                # side); the following ones ADD their visible rows to it (g4s_rasterizer_backward_accumulate): the
-                # accumulating per-Gaussian kernel waits for the previous view's slot, the blend kernels do not.
+                # Every view goes through g4s_rasterizer_backward_accumulate: the first one of the step starts the sums
+                # (every row of the step's bucket written, dL_dsh cleared on the side), the following ones ADD their
+                # visible rows; the per-view densification statistics (norm per view BEFORE any reduction,
+                # gaussian_model.py:649-651) are summed by the same kernel.  Only that per-Gaussian kernel waits for
+                # the previous view's slot; the blend kernels of the views overlap.
                 out = dict(grad_out)
                 out["workspace"] = work
+                out["view_stats"] = side
+                out["accumulate"] = True if j > 0 else "first"
                 if j > 0:
-                    out["accumulate"] = True
                     out["after"] = pipe.previous_view_done
-                grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
-                                                        1.0, empty, cam["view"], cam["proj"], cam["tanfovx"],
-                                                        cam["tanfovy"], dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"],
-                                                        fw[4], fw[0], fw[5], fw[6], False, out=out)
-                # per-view densification statistics BEFORE any reduction (gaussian_model.py:649-651), summed view after view
-                tmp = slot_tmp[j % pipe.k]
-                torch.linalg.vector_norm(grads[0][:, :2], dim=1, out=tmp[:, 0])
-                torch.gt(radii, 0, out=tmp_vis[j % pipe.k])
-                tmp[:, 1] = tmp_vis[j % pipe.k]
-                pipe.after_previous_view()  # (the waits are satisfied already when j > 0: the backward has waited)
-                if j == 0:
-                    side.copy_(tmp)
-                else:
-                    side.add_(tmp)
+                _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
+                                                1.0, empty, cam["view"], cam["proj"], cam["tanfovx"],
+                                                cam["tanfovy"], dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"],
+                                                fw[4], fw[0], fw[5], fw[6], False, out=out)
                 res.append((fw[0], radii))
         pipe.join()
         if dist is not None:
@@ -406,8 +398,6 @@ def main():
             del fw
         from g4splat_amd.pipeline import ViewPipeline
         pipe = ViewPipeline(P, W, H, int(max(Rs.values()) * 1.25) + 4096, device, k=min(3, views_per_rank))
-        slot_tmp = [torch.zeros((P, 2), device=device) for _ in range(pipe.k)]
-        tmp_vis = [torch.zeros((P,), dtype=torch.bool, device=device) for _ in range(pipe.k)]
         torch.cuda.synchronize()
     if dist is not None and exchange == "owner":
         try:

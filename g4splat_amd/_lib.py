@@ -41,7 +41,7 @@ SIGNATURES = {
                                                c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_p]),
     "g4s_rasterizer_backward_accumulate": (c_i, [c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p,
                                                  c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                                 c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_i, c_p]),
+                                                 c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p, c_i, c_p]),
     "g4s_rasterizer_forward_presized": (c_i, [c_p, c_sz, c_p, c_sz, c_p, c_sz, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p,
                                               c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_i,
                                               c_p]),

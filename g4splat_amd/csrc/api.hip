@@ -503,7 +503,7 @@ static int rasterizer_backward_impl(
     const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
     float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
     float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream_, bool accumulate = false,
-    void* after_event = nullptr) {
+    void* after_event = nullptr, float* view_stats = nullptr) {
     (void)scale_modifier;
     hipStream_t stream = (hipStream_t)stream_;
     t_err[0] = 0;
@@ -606,6 +606,7 @@ static int rasterizer_backward_impl(
     pb.rec_flag = rec_flag; pb.n_slots = (uint32_t)R;
     pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest; pb.sh_prezeroed = sh_prezeroed;
     pb.accumulate = accumulate;
+    pb.view_stats = view_stats;
     // The blend backward above touches only this call's own state; the per-Gaussian kernel below adds into tensors that
     // the previous view's backward -- on another stream -- may still be adding into: it waits for the caller's event.
     if (after_event) HIP_TRY(hipStreamWaitEvent(stream, (hipEvent_t)after_event, 0));
@@ -660,7 +661,8 @@ extern "C" int g4s_rasterizer_backward_accumulate(
     float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
     const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
     float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale,
-    float* dL_drot, char* workspace, size_t workspace_bytes, void* after_event, int debug, void* stream) {
+    float* dL_drot, float* view_stats, int first_view, char* workspace, size_t workspace_bytes, void* after_event, int debug,
+    void* stream) {
     t_err[0] = 0;
     if (P > 0 && (!sh_dc || M < 1 || (sh_rest && M > 1 && !dL_dsh_rest)))
         return fail(G4S_ERR_INVALID_ARGUMENT, "accumulating backward needs SH coefficients (packed, or sh_dc + sh_rest / dL_dsh_rest)");
@@ -669,7 +671,7 @@ extern "C" int g4s_rasterizer_backward_accumulate(
                                     tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths,
                                     dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh_dc,
                                     (sh_rest && M > 1) ? dL_dsh_rest : nullptr, dL_dscale, dL_drot, workspace, workspace_bytes,
-                                    debug, stream, true, after_event);
+                                    debug, stream, first_view == 0, after_event, view_stats);
 }
 
 extern "C" int g4s_rasterizer_mark_visible(int P, const float* means3D, const float* viewmatrix,

@@ -254,6 +254,7 @@ struct PreprocessBwdArgs {
     const float* shs_rest;  // split layout: shs / dL_dsh are the [P,1,3] parts, shs_rest / dL_dsh_rest the [P,M-1,3] ones
     float* dL_dsh_rest;
     bool sh_prezeroed;  // dL_dsh (and dL_dsh_rest) were cleared by the blend backward: K8 writes visible rows only
+    float* view_stats;  // optional [P,2]: (||dL_dmean2D.xy|| of this view, visible ? 1 : 0), written or -- accumulate -- added
     bool accumulate;    // parameter gradients are ADDED to their tensors (views accumulated in place); nothing is cleared
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
         *dL_drot;

@@ -612,7 +612,9 @@ constexpr int K8_SUM_STRIDE = GRAD_FLOATS + 1;  // LDS row stride, odd => confli
 // LDS staging of the block's outputs (floats per Gaussian: mean2D 3, normal 3, opacity 1, colour 3, mean3D 3, T 9, scale 2,
 // rotation 4 = 28), one row-major [256, w] region per tensor
 constexpr int K8_OUT_MEAN2D = 0, K8_OUT_NORMAL = 768, K8_OUT_OPACITY = 1536, K8_OUT_COLOR = 1792, K8_OUT_MEAN3D = 2560,
-              K8_OUT_TRANSMAT = 3328, K8_OUT_SCALE = 5632, K8_OUT_ROT = 6144, K8_OUT_FLOATS = 28;
+              K8_OUT_TRANSMAT = 3328, K8_OUT_SCALE = 5632, K8_OUT_ROT = 6144, K8_OUT_STATS = 7168, K8_OUT_FLOATS = 30;
+// (K8_OUT_STATS: the optional per-view densification statistics [256, 2] = (||dL_dmean2D.xy||, visible) of
+// g4s_rasterizer_backward_accumulate)
 
 // K8, phase 1: the fold.
 //
@@ -980,6 +982,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         for (int i = 0; i < 9; i++) o[K8_OUT_TRANSMAT + 9 * t + i] = dT_out[i];
         o[K8_OUT_SCALE + 2 * t] = dscale[0]; o[K8_OUT_SCALE + 2 * t + 1] = dscale[1];
         *reinterpret_cast<float4*>(o + K8_OUT_ROT + 4 * t) = drot;
+        // gaussian_model.py:649-651: the norm of THIS view's screen-space gradient (its z is 0) and the visibility count
+        o[K8_OUT_STATS + 2 * t] = visible ? sqrtf(dmean2[0] * dmean2[0] + dmean2[1] * dmean2[1]) : 0.0f;
+        o[K8_OUT_STATS + 2 * t + 1] = visible ? 1.0f : 0.0f;
     }
     __syncthreads();
     {
@@ -1012,6 +1017,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         flush(a.dL_dtransMat, 9, K8_OUT_TRANSMAT, false);
         flush(a.dL_dscale, 2, K8_OUT_SCALE, ACC);
         flush(a.dL_drot, 4, K8_OUT_ROT, ACC);
+        flush(a.view_stats, 2, K8_OUT_STATS, ACC);
     }
 }
 

@@ -229,9 +229,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     `out["accumulate"] = True` (extension: g4s_rasterizer_backward_accumulate): the parameter gradients -- dL_dmeans3D,
     dL_dopacity, dL_dsh (or dL_dsh_dc / dL_dsh_rest), dL_dscales, dL_drotations, all five REQUIRED in `out` -- are added
     to what those tensors hold instead of overwriting them (rows of Gaussians this view does not see are not touched,
-    nothing is zero-filled): the second and later views of a multi-view batch.  `out["after"]`: a recorded
-    torch.cuda.Event -- the stream waits for it between the blend backward and the accumulating per-Gaussian kernel
-    (views in flight on several streams: pipeline.ViewPipeline hands out the previous view's event).
+    nothing is zero-filled): the second and later views of a multi-view batch.  `out["accumulate"] = "first"`: the same
+    entry point starting the sums (every row written, like the plain call).  `out["view_stats"]`: float32 [P,2], the
+    batch's densification statistics (sum of the per-view ||dL_dmeans2D.xy||, number of views that saw the Gaussian),
+    written by the "first" call and added to by the others.  `out["after"]`: a recorded torch.cuda.Event -- the stream
+    waits for it between the blend backward and the accumulating per-Gaussian kernel (views in flight on several
+    streams: pipeline.ViewPipeline hands out the previous view's event).
 
     The backward reads AND updates the forward's state chunks (the validity bytes of its gradient records live in the
     binning chunk): run at most one backward at a time per forward state, and with a PresizedState -- whose chunks
@@ -260,8 +263,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         fopt = dict(dtype=torch.float32, device=dev)
         alloc = torch.zeros if P == 0 else torch.empty  # the library writes every element when P > 0
         given = dict(out) if out else {}
-        accumulate = bool(given.pop("accumulate", False))
+        accumulate = given.pop("accumulate", False)
+        if accumulate not in (False, True, "first"):
+            raise RuntimeError("out['accumulate'] must be True, False or 'first'")
+        first_view = accumulate == "first"
+        accumulate = bool(accumulate)
         after = given.pop("after", None)
+        view_stats = given.pop("view_stats", None)
+        if view_stats is not None and not accumulate:
+            raise RuntimeError("out['view_stats'] only applies to an accumulating backward (accumulate = True or 'first')")
+        if view_stats is not None and (tuple(view_stats.shape) != (P, 2) or view_stats.dtype != torch.float32
+                                       or view_stats.device != dev or not view_stats.is_contiguous()):
+            raise RuntimeError(f"out['view_stats'] must be a contiguous float32 ({P}, 2) tensor on {dev}")
         if accumulate:
             need = ["dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations"] + (["dL_dsh_dc", "dL_dsh_rest"] if split else ["dL_dsh"])
             missing = [n for n in need if n not in given]
@@ -280,7 +293,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     or not t.is_contiguous() or (t.numel() and t.data_ptr() % align)):
                 raise RuntimeError(f"out['{name}'] must be a contiguous float32 {tuple(shape)} tensor on {dev}, "
                                    f"{align}-byte aligned")
-            if P == 0 and not accumulate:
+            if P == 0 and (first_view or not accumulate):
                 t.zero_()
             return t
 
@@ -329,7 +342,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                     float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
                     _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
                     _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(gdc), _ptr(grest), _ptr(dL_dscales),
-                    _ptr(dL_drotations), _ptr(workspace), ws_bytes, ev, int(bool(debug)), stream)
+                    _ptr(dL_drotations), _ptr(view_stats), int(first_view), _ptr(workspace), ws_bytes, ev,
+                    int(bool(debug)), stream)
             elif split:
                 dc, rest = _f32c(sh_dc), _f32c(sh_rest)
                 rc = lib.g4s_rasterizer_backward_split_sh(

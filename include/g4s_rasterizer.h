@@ -155,21 +155,24 @@ int g4s_rasterizer_backward_split_sh(
 /*
  * Backward that ACCUMULATES (extension; the reference has no counterpart -- it trains one view per optimiser step,
  * train_with_refine_depth.py:373-378, and leaves the summing of several views to autograd's dense `grad += g`).
- * For multi-view batches (gradient accumulation; SURVEY.md 8(e)'s 8 views over fewer than 8 GPUs): the five PARAMETER
- * gradients -- dL_dmean3D, dL_dopacity, dL_dsh (or dL_dsh_dc / dL_dsh_rest), dL_dscale, dL_drot -- are ADDED to what the
- * tensors hold, rows of Gaussians the view does not see are not touched, and nothing is zero-filled: per view that is
- * V x 232 B of read-modify-write instead of a P x 232 B write plus autograd's 3 x P x 232 B dense add.  The per-view
- * outputs (dL_dmean2D -- the densification statistic is a norm PER VIEW, gaussian_model.py:649-651 --, dL_dcolor,
- * dL_dtransMat) are overwritten as in g4s_rasterizer_backward.  The first view of a batch goes through
- * g4s_rasterizer_backward[_split_sh] (which writes every row), the following ones through this call.
+ * For multi-view batches (gradient accumulation; SURVEY.md 8(e)'s 8 views over fewer than 8 GPUs).  With
+ * first_view == 0 the five PARAMETER gradients -- dL_dmean3D, dL_dopacity, dL_dsh (or dL_dsh_dc / dL_dsh_rest),
+ * dL_dscale, dL_drot -- are ADDED to what the tensors hold, rows of Gaussians the view does not see are not touched, and
+ * nothing is zero-filled: per view that is V x 232 B of read-modify-write instead of a P x 232 B write plus autograd's
+ * 3 x P x 232 B dense add.  With first_view != 0 the call writes every row exactly like
+ * g4s_rasterizer_backward[_split_sh] (the first view of a batch starts the sums).  The per-view outputs (dL_dmean2D,
+ * dL_dcolor, dL_dtransMat) are overwritten either way.
  *
  *   sh_dc, sh_rest      sh_rest == NULL: sh_dc is the packed [P,M,3] tensor and dL_dsh_dc the packed [P,M,3] gradient;
  *                       otherwise the split layout of g4s_rasterizer_backward_split_sh
+ *   view_stats          [P,2] or NULL: the densification statistics of the batch, (sum over the views of THIS VIEW's
+ *                       ||dL_dmean2D.xy|| -- the reference accumulates a norm per view, gaussian_model.py:649-651, not the
+ *                       norm of a sum --, number of views that saw the Gaussian); written when first_view, added otherwise
  *   after_event         hipEvent_t or NULL.  The sums are ordered by the caller: views of a batch may be in flight on
  *                       different streams (their blend kernels overlap), but the accumulating per-Gaussian kernel of
  *                       view j must run after that of view j-1.  If non-NULL, `stream` waits for this event -- recorded
  *                       by the caller behind the previous view's backward -- between the blend backward and the
- *                       accumulating kernel, so only the latter is serialised.  Sums in a fixed order are bit-reproducible.
+ *                       per-Gaussian kernel, so only the latter is serialised.  Sums in a fixed order are bit-reproducible.
  * Everything else as g4s_rasterizer_backward_split_sh.  Colours come from SH (no colors_precomp).
  */
 int g4s_rasterizer_backward_accumulate(
@@ -183,6 +186,7 @@ int g4s_rasterizer_backward_accumulate(
     const float* dL_dpix, const float* dL_depths,
     float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
     float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale, float* dL_drot,
+    float* view_stats, int first_view,
     char* workspace, size_t workspace_bytes, void* after_event, int debug, void* stream);
 
 /*

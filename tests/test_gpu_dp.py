@@ -283,11 +283,13 @@ def test_accumulating_backward_equals_the_sequential_sum_bit_for_bit(hip_lib, sp
 
     # separate backwards, summed by torch in view order
     want, mean2d, seen, Rmax = None, [], torch.zeros(P, dtype=torch.bool, device=device), 0
+    count = torch.zeros(P, device=device)
     for c in dcams:
         fw = fwd(c)
         Rmax = max(Rmax, int(fw[0]))
         gr = bwd(c, fw)
         seen |= fw[3] > 0
+        count += (fw[3] > 0).float()
         mean2d.append(gr[0].clone())
         d = pick(gr)
         want = {k: v.clone() for k, v in d.items()} if want is None else {k: want[k] + d[k] for k in want}
@@ -310,13 +312,15 @@ def test_accumulating_backward_equals_the_sequential_sum_bit_for_bit(hip_lib, sp
     pipe = ViewPipeline(P, W, H, int(Rmax * 1.25) + 4096, device, k=3)
     for rep in range(2):
         sums2 = {k: torch.full_like(v, float("nan")) for k, v in want.items()}
+        stats = torch.full((P, 2), float("nan"), device=device)
         for j, c in enumerate(dcams):
             with pipe.slot(j) as (state, work):
                 fw = fwd(c, state)
                 out = dict(sums2)
                 out["workspace"] = work
+                out["view_stats"] = stats
+                out["accumulate"] = True if j else "first"   # the same entry point starts the sums
                 if j:
-                    out["accumulate"] = True
                     out["after"] = pipe.previous_view_done
                 gr = bwd(c, fw, out=out)
         pipe.join()
@@ -324,6 +328,12 @@ def test_accumulating_backward_equals_the_sequential_sum_bit_for_bit(hip_lib, sp
         assert not pipe.overflowed()
         for k in names:
             assert torch.equal(sums2[k], want[k]), (rep, k)
+        # the fused densification statistics: sum over the views of the per-view ||dL_dmeans2D.xy||, and the view count
+        want_norm = torch.zeros(P, device=device)
+        for m in mean2d:
+            want_norm += torch.sqrt(m[:, 0] * m[:, 0] + m[:, 1] * m[:, 1])
+        assert torch.allclose(stats[:, 0], want_norm, rtol=2e-6, atol=0) and float(want_norm.max()) > 0
+        assert torch.equal(stats[:, 1], count)
 
     # refusals: the running sums must be handed in, and `after` belongs to an accumulating call
     fw = fwd(dcams[0])
@@ -331,6 +341,8 @@ def test_accumulating_backward_equals_the_sequential_sum_bit_for_bit(hip_lib, sp
         bwd(dcams[0], fw, out={"accumulate": True})
     with pytest.raises(RuntimeError, match="only applies"):
         bwd(dcams[0], fw, out={"after": torch.cuda.Event()})
+    with pytest.raises(RuntimeError, match="only applies"):
+        bwd(dcams[0], fw, out={"view_stats": torch.zeros(P, 2, device=device)})
 
 
 def test_multi_view_batch_through_render_and_autograd_on_two_streams():
@@ -472,7 +484,7 @@ def test_view_parallel_accumulate_pipelines_by_default_and_matches_the_sequentia
         torch.cuda.synchronize()
         state = [model.optimizer.state[p] for p in model.parameters()]
         return ([p.detach().clone() for p in model.parameters()],
-                [st[k].clone() for st in state for k in ("exp_avg", "exp_avg_sq")], keep, vp, model
+                [st[k].clone() for st in state for k in ("exp_avg", "exp_avg_sq")], keep, vp, model)
 
     pa, ma, sa, vpa, _ = train(1)
     pb, mb, sb, vpb, model_b = train(2)
@@ -484,7 +496,7 @@ def test_view_parallel_accumulate_pipelines_by_default_and_matches_the_sequentia
         assert torch.equal(a, b)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
-    assert float(sa["vis_count"].max()) == 4.0 and float(sa["grad_norm_sum"].max()) > 0
+    assert float(sa["vis_count"].max()) >= 2.0 and float(sa["grad_norm_sum"].max()) > 0
     # a dropped gradient buffer is refused before a view is issued
     model_b.optimizer.zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError, match="no .grad buffer"):
