@@ -18,8 +18,11 @@ step, zero_grad -- is captured once per (P, resolution, intrinsics) and replayed
 
 `body(out, gt)` turns render()'s dict and the target into the scalar loss (any torch / g4splat_amd.losses code without
 host synchronisation).  The graph's inputs are the camera's world_view_transform, full_proj_transform, camera_center and
-the target image; image size and field of view are baked in at capture (cameras with other intrinsics need their own
-TrainStepGraph).  `step.overflowed()` reads the PresizedState's overflow flag (synchronises): a frame that binned more
+the target image.  EVERYTHING ELSE is baked in at capture and needs a new TrainStepGraph when it changes: image size and
+field of view (cameras with other intrinsics), the number of Gaussians and the storage of the optimiser's parameter
+tensors (any densify / prune / reset_opacity that replaces them: a replay would train on freed memory), the active SH
+degree (oneupSHdegree()), `pipe.depth_ratio` and whatever `body` closes over (loss weights).  The first three groups
+are recorded at capture and checked on every call -- a stale graph raises instead of replaying.  `step.overflowed()` reads the PresizedState's overflow flag (synchronises): a frame that binned more
 instances than `instance_capacity` is invalid and so is the update made from it.
 """
 from types import SimpleNamespace
@@ -72,6 +75,15 @@ class TrainStepGraph:
         with torch.cuda.graph(self.graph):
             self.loss = self._iteration()
         self.replays = 0
+        self._captured = self._signature()
+
+    def _signature(self):
+        """What a replay silently depends on besides its inputs: P, the active SH degree, depth_ratio and the addresses of
+        the optimiser's parameter tensors."""
+        g = self.gaussians
+        params = [p for grp in g.optimizer.param_groups for p in grp["params"]]
+        return (int(g.get_xyz.shape[0]), int(g.active_sh_degree), float(getattr(self.pipe, "depth_ratio", 0.0)),
+                tuple(int(p.data_ptr()) for p in params))
 
     def _snapshot(self):
         g = self.gaussians
@@ -116,6 +128,13 @@ class TrainStepGraph:
         if (int(camera.image_width), int(camera.image_height)) != (c.image_width, c.image_height) or \
                 abs(float(camera.FoVx) - c.FoVx) > 1e-12 or abs(float(camera.FoVy) - c.FoVy) > 1e-12:
             raise RuntimeError("TrainStepGraph was captured for another image size / field of view")
+        now = self._signature()
+        if now != self._captured:
+            what = [n for n, a, b in zip(("number of Gaussians", "active SH degree", "pipe.depth_ratio",
+                                          "optimiser parameter tensors (densify / prune / reset_opacity replaced them)"),
+                                         self._captured, now) if a != b]
+            raise RuntimeError("TrainStepGraph is stale -- changed since capture: " + ", ".join(what) +
+                               "; build a new TrainStepGraph")
         c.world_view_transform.copy_(camera.world_view_transform, non_blocking=True)
         c.full_proj_transform.copy_(camera.full_proj_transform, non_blocking=True)
         c.camera_center.copy_(camera.camera_center, non_blocking=True)

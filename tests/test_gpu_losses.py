@@ -31,6 +31,22 @@ def test_golden_vectors_of_the_reference(hip_lib, name):
     assert not l1.requires_grad and not ss.requires_grad
 
 
+def test_metrics_ssim_is_the_fused_kernel_and_matches_the_reference(hip_lib):
+    """g4splat_amd.metrics.ssim (the reference's name, loss_utils.py:46-79) == the reference's value (golden), with a
+    gradient; psnr / l1_loss follow their inputs to the device."""
+    from g4splat_amd import metrics
+    g = np.load(os.path.join(G, "losses.npz"))
+    a = torch.tensor(g["a"], device="cuda:0", requires_grad=True)
+    b = torch.tensor(g["b"], device="cuda:0")
+    s = metrics.ssim(a, b)
+    assert abs(float(s) - float(g["ssim"])) <= 1e-5
+    s.backward()
+    assert a.grad is not None and float(a.grad.abs().max()) > 0
+    assert abs(float(metrics.ssim(a.detach()[None], b[None])) - float(g["ssim"])) <= 1e-5
+    np.testing.assert_allclose(metrics.psnr(a.detach()[None], b[None]).cpu().numpy(), g["psnr"], rtol=1e-5)
+    np.testing.assert_allclose(metrics.l1_loss(a.detach(), b).cpu().numpy(), g["l1"], rtol=1e-5)
+
+
 def test_metric_resolution_vs_restatement_and_speed(hip_lib, capsys):
     import ctypes
     import json

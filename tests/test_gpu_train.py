@@ -434,7 +434,15 @@ def test_training_iteration_replayed_from_a_hip_graph_equals_the_eager_loop():
             m.densify_and_prune(2e-6, 0.005, 3.0, 20)
     n_new = a.get_xyz.shape[0]
     assert n_new == b.get_xyz.shape[0] and n_new != P
+    # the old graph holds the freed parameter tensors and the old P: a replay must be refused, not run
+    with pytest.raises(RuntimeError, match="stale.*number of Gaussians"):
+        step(cams[0], gts[0])
     step = TrainStepGraph(b, body, cams[0], (3, H, W), instance_capacity=300_000)
+    deg = b.active_sh_degree
+    b.active_sh_degree = deg - 1 if deg > 0 else deg + 1
+    with pytest.raises(RuntimeError, match="stale.*active SH degree"):
+        step(cams[0], gts[0])
+    b.active_sh_degree = deg
     for it in range(iters, iters + 4):
         a.update_learning_rate(it + 1)
         out = render(cams[it % 3], a, pipe, bg)
