@@ -34,10 +34,13 @@ def run_oracle(oracle_mod, inp, grads=None):
     return out
 
 
-def run_hip(inp, grads=None, debug=False, device="cuda:0"):
-    """Calls the C ABI through the `_C` front-end exactly like the autograd node does."""
+def run_hip(inp, grads=None, debug=False, device="cuda:0", backend=None):
+    """Calls the C ABI through the `_C` front-end exactly like the autograd node does.  `backend`: another module with
+    the same surface (the compiled pybind stub of INTEGRATION.md section B) instead of the ctypes front-end."""
     import torch
     from g4splat_amd.diff_surfel_rasterization import _C
+    if backend is not None:
+        _C = backend
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
     args = dict((k, t(v)) for k, v in inp.items() if isinstance(v, np.ndarray))
     fw = _C.rasterize_gaussians(args["bg"], args["means3D"], args["colors"], args["opacity"], args["scales"],

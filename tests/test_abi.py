@@ -143,3 +143,19 @@ def test_oracle_library_builds_and_is_not_linked_into_product(hip_lib, oracle_mo
                 assert "libsurfel_oracle" not in txt, f
             elif txt:
                 assert not re.search(r"#\s*include\s+[\"<][^\">]*oracle", txt), f
+
+
+def test_pybind_stub_of_integration_b_builds_and_exports_the_reference_surface(hip_lib):
+    """INTEGRATION.md section B is compiled, not prose: g4splat_amd/pybind/{rasterize_points.cpp, ext.cpp} build as plain
+    C++ (torch.utils.cpp_extension, nothing hipified) against libg4s_hip.so and export the three names of
+    dsr/ext.cpp:15-19; the module links the product library and not the oracle.  (Compute: tests/test_gpu_pybind.py.)"""
+    from g4splat_amd import build
+    so = build.build_pybind()
+    mod = build.pybind_module()
+    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(mod))
+    out = subprocess.run(["ldd", so], stdout=subprocess.PIPE, text=True).stdout
+    assert "libg4s_hip.so" in out and "not found" not in out.split("libg4s_hip.so")[1].splitlines()[0]
+    assert "surfel_oracle" not in out
+    for f in ("rasterize_points.cpp", "ext.cpp"):
+        txt = open(os.path.join(ROOT, "g4splat_amd", "pybind", f)).read()
+        assert "cuda_runtime" not in txt and "__global__" not in txt and "<<<" not in txt  # no kernels: plumbing only
