@@ -10,6 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "exhaustive: the remaining views of the eight-view configurations; only selected "
+                                       "when the -m expression names it (-m \"gpu and exhaustive\" / -m \"gpu or exhaustive\")")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` alone must stay inside the driver's step limit: tests marked `exhaustive` are deselected unless the
+    marker expression mentions them."""
+    if "exhaustive" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("exhaustive") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope="session")

@@ -141,7 +141,8 @@ def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
     assert ex["bytes_per_rank"]["all_to_all_sent"] > 0 and ex["bytes_per_rank"]["all_gather_received"] > 0
     t = d["timing"]
     assert len(t["per_step_ms"]) == 3 and t["mean_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
-    assert 1 <= t["undisturbed_passes"] <= t["passes"] == len(t["attempts"])
+    assert 0 <= t["undisturbed_passes"] <= t["passes"] == len(t["attempts"])  # (two gloo ranks on one GPU jitter)
+    assert t["disturbed"] == (t["undisturbed_passes"] == 0)
     assert t["min_ms"] <= t["median_ms"] <= t["max_ms"] and isinstance(t["disturbed"], bool)
     assert d["build_id"] and d["build_id"] != "unknown"
     assert d["cpu_baseline"] is None and d["roofline"] is not None
