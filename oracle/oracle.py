@@ -159,6 +159,17 @@ def instance_flags(o):
     return flags[:R]
 
 
+def lane_model(o):
+    """-> dict of the blend backward's lane-utilisation model for Oracle `o`'s forward (oracle_lane_model in
+    surfel_oracle.c; tools/lane_util_model.py prints it)."""
+    out = np.zeros(11, np.float64)
+    lib().oracle_lane_model(o._s, ctypes.c_void_p(out.ctypes.data))
+    names = ("entries", "pairs", "visits_quadrants", "visits_row_strips", "visits_col_strips", "visits_free_halves",
+             "visits_free_cells", "visits_lower_bound", "visits_saved_by_entry_pairing", "visits_in_one_half",
+             "visits_in_one_row")
+    return dict(zip(names, out.tolist()))
+
+
 def pixel_margins(o):
     """float32[3, H*W]: per pixel, the smallest relative distance to a threshold met by each kind of discrete
     decision of the forward loop (0: skip a splat -- alpha vs 1/255, depth vs near; 1: stop the pixel -- T(1-alpha)

@@ -1030,6 +1030,108 @@ void oracle_knn_queries(int P, const float *points, int nq, const int *queries, 
     }
 }
 
+/* Lane-utilisation model of the blend backward (tools/lane_util_model.py, profiles/r04_lane_util_model.txt).
+ * For every (list entry, tile) that some pixel blends, the 256-bit mask of the pixels that blend it -- exactly the
+ * backward's `act` predicate: list position below the pixel's last contributor and the alpha test passed -- is formed and
+ * the issue slots different static work units would need are counted.  A "visit" is one pass of the wave (64 lanes) over
+ * the per-pixel arithmetic; useful lanes = blending pixels / (64 x visits).
+ *   out[0]  entries (with at least one blending pixel)          out[1]  blending (entry, pixel) pairs
+ *   out[2]  visits, 8x8 quadrants (the shipped kernel: lane = the same position in each of the four quadrants)
+ *   out[3]  visits, 16x4 row strips            out[4]  visits, 4x16 column strips
+ *   out[5]  visits if the two half-waves could choose their 8x4 half-quadrant independently (lanes 0..31 own the top
+ *           halves of the four quadrants, lanes 32..63 the bottom halves: max(#top halves hit, #bottom halves hit))
+ *   out[6]  visits if the four 16-lane rows could choose their 4x4 cell independently (row r owns cell r of each
+ *           quadrant: max over r of the quadrants whose cell r is hit)
+ *   out[7]  lower bound: ceil(blending pixels / 64) per entry (perfect packing)
+ *   out[8]  quadrant visits saved if two CONSECUTIVE blending entries of a tile whose masks are disjoint inside a
+ *           quadrant shared one visit there (greedy pairing, back to front)
+ *   out[9]  quadrant visits in which at most 32 lanes blend and they all sit in one half (top or bottom 8x4)
+ *   out[10] quadrant visits in which the blending lanes sit in a single 16-lane row (8x2 pixels) */
+void oracle_lane_model(const OracleState *s, double *out /*11*/) {
+    const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+    double acc[11];
+    memset(acc, 0, sizeof acc);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0, a9 = 0, a10 = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+:a0,a1,a2,a3,a4,a5,a6,a7,a8,a9,a10)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        unsigned char prev[256];
+        int have_prev = 0;
+        for (uint32_t ii = r1; ii > r0; ii--) {  /* back to front, as the backward walks the list */
+            uint32_t i = ii - 1;
+            uint32_t id = s->point_list[i];
+            const float *no = s->normal_opacity + 4 * (size_t)id;
+            unsigned char m[256];
+            int n = 0;
+            for (int l = 0; l < 256; l++) {
+                int lx = l & 15, ly = l >> 4;
+                int px = tx * 16 + lx, py = ty * 16 + ly;
+                m[l] = 0;
+                if (px >= W || py >= H) continue;
+                size_t pix = (size_t)W * py + px;
+                if ((i - r0) >= s->n_contrib[pix]) continue;
+                PairEval e;
+                if (!eval_pair((float)px, (float)py, s->means2D + 2 * (size_t)id, s->transMat + 9 * (size_t)id, no[3], &e)) continue;
+                m[l] = 1;
+                n++;
+            }
+            if (n == 0) continue;
+            a0 += 1; a1 += n; a7 += (n + 63) / 64;
+            int quad[4] = {0, 0, 0, 0}, rowstrip[4] = {0, 0, 0, 0}, colstrip[4] = {0, 0, 0, 0};
+            int top[4] = {0, 0, 0, 0}, bot[4] = {0, 0, 0, 0}, cell[4][4], rows8x2[4][4];
+            memset(cell, 0, sizeof cell);
+            memset(rows8x2, 0, sizeof rows8x2);
+            for (int l = 0; l < 256; l++) {
+                if (!m[l]) continue;
+                int lx = l & 15, ly = l >> 4, q = (lx >> 3) + 2 * (ly >> 3);
+                quad[q]++;
+                rowstrip[ly >> 2] = 1; colstrip[lx >> 2] = 1;
+                if ((ly & 7) < 4) top[q]++; else bot[q]++;
+                cell[q][((lx >> 2) & 1) + 2 * ((ly >> 2) & 1)] = 1;
+                rows8x2[q][(ly & 7) >> 1] = 1;  /* lane = (lx & 7) + 8 (ly & 7): 16-lane row = (ly & 7) >> 1 */
+            }
+            int nq = 0, ntop = 0, nbot = 0;
+            for (int q = 0; q < 4; q++) {
+                nq += quad[q] != 0; ntop += top[q] != 0; nbot += bot[q] != 0;
+                a3 += rowstrip[q]; a4 += colstrip[q];
+                if (quad[q] && quad[q] <= 32 && (top[q] == 0 || bot[q] == 0)) a9 += 1;
+                if (quad[q] && rows8x2[q][0] + rows8x2[q][1] + rows8x2[q][2] + rows8x2[q][3] == 1) a10 += 1;
+            }
+            a2 += nq;
+            a5 += ntop > nbot ? ntop : nbot;
+            int best = 0;
+            for (int r = 0; r < 4; r++) {
+                int c = (cell[0][r] != 0) + (cell[1][r] != 0) + (cell[2][r] != 0) + (cell[3][r] != 0);
+                if (c > best) best = c;
+            }
+            a6 += best;
+            if (have_prev) {  /* could this entry share its quadrant visits with the previous (deeper) blending entry? */
+                int saved = 0;
+                for (int q = 0; q < 4; q++) {
+                    int both = 0, pq = 0, disjoint = 1;
+                    for (int l = 0; l < 256; l++) {
+                        int lx = l & 15, ly = l >> 4;
+                        if ((lx >> 3) + 2 * (ly >> 3) != q) continue;
+                        pq |= prev[l]; both |= m[l];
+                        if (prev[l] && m[l]) disjoint = 0;
+                    }
+                    if (pq && both && disjoint) saved++;
+                }
+                a8 += saved;
+                have_prev = saved ? 0 : 1;  /* greedy: a merged pair is used up */
+                if (have_prev) memcpy(prev, m, 256);
+            } else {
+                memcpy(prev, m, 256);
+                have_prev = 1;
+            }
+        }
+    }
+    acc[0] = a0; acc[1] = a1; acc[2] = a2; acc[3] = a3; acc[4] = a4; acc[5] = a5; acc[6] = a6; acc[7] = a7; acc[8] = a8;
+    acc[9] = a9; acc[10] = a10;
+    memcpy(out, acc, sizeof acc);
+}
+
 /* Workload statistics at 4x4-cell granularity (design study for the blend forward, not part of the restatement):
  * out[0] = (entry, quadrant) pairs with a pixel that passes the alpha test before the pixel's last contributor,
  * out[1] = (entry, 4x4 cell) pairs with such a pixel, out[2] = such (entry, pixel) pairs,

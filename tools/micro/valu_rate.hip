@@ -65,6 +65,40 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned long lo
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 static unsigned long long* d_cyc;
+// Does a VALU instruction get cheaper when whole 16-lane rows of the wave are masked off?  (If it did, clustering the
+// active pixels of the blend kernels into few rows would pay.)  MASK: bit r = row r (lanes 16 r .. 16 r + 15) executes.
+template <int MASK>
+__global__ void __launch_bounds__(256) k_rows(float* out, int iters, unsigned long long* cyc) {
+    float a[8];
+    for (int i = 0; i < 8; i++) a[i] = 1.0f + threadIdx.x * 1e-3f + i;
+    const int row = (threadIdx.x & 63) >> 4;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    if ((MASK >> row) & 1) {
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a[i]));
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (cyc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *cyc = t1 - t0;
+    float s = 0;
+    for (int i = 0; i < 8; i++) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int MASK>
+void run_rows(const char* name, float* d) {
+    const int iters = 4096, blocks = 256 * 4;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_rows<MASK>, dim3(blocks), dim3(256), 0, 0, d, 16, (unsigned long long*)nullptr);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_rows<MASK>, dim3(blocks), dim3(256), 0, 0, d, iters, (unsigned long long*)nullptr);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-44s %.3f ms  %.2f cyc/instr at a nominal 2.4 GHz\n", name, ms, ms * 1e-3 * 2.4e9 / ((double)iters * 8 * 4));
+}
 template <int KIND>
 void run(const char* name, float* d, int per_iter = 8) {
     const int iters = 4096, blocks = 256 * 4;  // 4 blocks of 4 waves per CU: 4 waves per SIMD
@@ -117,5 +151,9 @@ int main() {
     run<25>("8 v_fma + 2 ds_read_b128 (per group of 8)", d, 1);
     run<26>("8 v_fma + 4 ds_read_b128 (per group of 8)", d, 1);
     run<27>("8 v_fma + 4 ds_read_b64 (per group of 8)", d, 1);
+    run_rows<0xF>("v_fma_f32, EXEC = all four 16-lane rows", d);
+    run_rows<0x3>("v_fma_f32, EXEC = rows 0-1 (lanes 0..31)", d);
+    run_rows<0x1>("v_fma_f32, EXEC = row 0 (lanes 0..15)", d);
+    run_rows<0x5>("v_fma_f32, EXEC = rows 0 and 2", d);
     return 0;
 }
