@@ -337,9 +337,11 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
     const int term_of_lane = 4 * row + quad_term(lane);
 
     // list positions >= the tile's max last_contributor cannot contribute anywhere
-    const int n_live = (int)wave_max_u32(max_last);
+    // (readfirstlane: the two maxima are wave-uniform, and what derives from them -- hi, m, pos, the median test --
+    // belongs in SGPRs: scalar compares and branches instead of vector compares inside EXEC regions)
+    const int n_live = __builtin_amdgcn_readfirstlane((int)wave_max_u32(max_last));
     // 1-based list position of the deepest median contributor of the tile: entries behind it skip the median term
-    const uint32_t tile_max_median = wave_max_u32(max_median);
+    const uint32_t tile_max_median = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(max_median));
     if (n_live > a.hot_threshold) {  // a deep tile would be this kernel's tail: four waves take it (blend_bwd_hot_kernel)
         if (lane == 0) a.hot_list[atomicAdd(a.hot_count, 1u)] = (uint32_t)tile;
         return;
@@ -406,8 +408,11 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                 const float4 cst = s_cst[q * 64 + lane];
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
-                bool act = pos < x.last_c;
-                if (act) act = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                // eval_pair runs on all 64 lanes, not under `pos < last_c`: a VALU instruction costs the same whatever
+                // EXEC says, and the mask region around it (s_and_saveexec, branch, restore) is pure overhead in a
+                // kernel whose waves are short of issue slots: -3.2 % (profiles/r04_ab_blend_bwd.txt)
+                const bool pass = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                const bool act = pass && pos < x.last_c;
                 // (qhit is exact, so some pixel of the quadrant is active; no wave vote needed)
                 if (act) {
                     const float G = e.G, alpha = e.alpha, c_d = e.depth;
@@ -637,8 +642,8 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                 }
                 bool lowpass = false;
                 PairEval e;
-                bool act = pos < x.last_c;
-                if (act) act = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                const bool pass = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                const bool act = pass && pos < x.last_c;
                 if (act) {  // the same arithmetic, in the same order, as the one-wave kernel's visit
                     const float G = e.G, alpha = e.alpha, c_d = e.depth;
                     const float inv1ma = fast_rcp(1.f - alpha);

@@ -329,6 +329,12 @@ __device__ __forceinline__ bool eval_rho(float pxf, float pyf, float cx, float c
 __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float cx, float cy, float Tux, float Tuy,
                                           float Tuz, float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz,
                                           float opa, PairEval& e) {
+    // No early exits: the three rejections (p.z == 0, depth < near, alpha < 1/255) are ANDed into the returned
+    // predicate at the end.  Every lane runs every instruction anyway (a VALU instruction costs the same whatever EXEC
+    // says); an early `return false` only buys an EXEC region -- s_and_saveexec, a branch, the restore -- around the
+    // rest, and those scalar instructions are what the blend kernels' waves are short of (-2 % blend_bwd, -x % blend_fwd,
+    // profiles/r04_ab_blend_bwd.txt).  A lane with p.z == 0 computes with inf / NaN and is rejected by `ok`; lanes that
+    // pass see exactly the arithmetic they saw before.
     e.kx = fmaf(pxf, Twx, -Tux);
     e.ky = fmaf(pxf, Twy, -Tuy);
     e.kz = fmaf(pxf, Twz, -Tuz);
@@ -338,7 +344,7 @@ __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float
     const float ppx = fmaf(e.ky, e.lz, -(e.kz * e.ly));
     const float ppy = fmaf(e.kz, e.lx, -(e.kx * e.lz));
     const float ppz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
-    if (ppz == 0.0f) return false;
+    bool ok = ppz != 0.0f;  // forward.cu:354 `if (p.z == 0.0) continue;`
     e.pz = ppz;
     // s = p.xy / p.z through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22 instructions), see eval_rho
     const float inv = __builtin_amdgcn_rcpf(ppz);
@@ -365,7 +371,7 @@ __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float
         rho = e.in3d ? e.rho3d : e.rho2d;
         e.depth = e.in3d ? e.depth : Twz;
         // (REC_NO_LOWPASS also certifies depth >= near wherever the splat can pass the alpha test)
-        if (e.depth < NEAR_N) return false;
+        ok = ok && !(e.depth < NEAR_N);  // forward.cu:378 `if (depth < near_n) continue;`
     }
     // forward.cu:383-385 `power = -0.5 rho; if (power > 0) continue;` can never fire (rho is a sum of squares),
     // and exp(power) = exp2(rho * (-0.5 log2 e)): scaling by -0.5 is exact, so folding it into the constant
@@ -373,8 +379,7 @@ __device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float
     // error ~3e-7 relative.
     e.G = __builtin_amdgcn_exp2f(rho * (-0.5f * 1.4426950408889634f));
     e.alpha = fminf(0.99f, opa * e.G);
-    if (e.alpha < 1.0f / 255.0f) return false;
-    return true;
+    return ok && !(e.alpha < 1.0f / 255.0f);  // forward.cu:391 `if (alpha < 1.0f / 255.0f) continue;`
 }
 
 }  // namespace g4s

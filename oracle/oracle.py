@@ -162,11 +162,11 @@ def instance_flags(o):
 def lane_model(o):
     """-> dict of the blend backward's lane-utilisation model for Oracle `o`'s forward (oracle_lane_model in
     surfel_oracle.c; tools/lane_util_model.py prints it)."""
-    out = np.zeros(11, np.float64)
+    out = np.zeros(15, np.float64)
     lib().oracle_lane_model(o._s, ctypes.c_void_p(out.ctypes.data))
     names = ("entries", "pairs", "visits_quadrants", "visits_row_strips", "visits_col_strips", "visits_free_halves",
              "visits_free_cells", "visits_lower_bound", "visits_saved_by_entry_pairing", "visits_in_one_half",
-             "visits_in_one_row")
+             "visits_in_one_row", "visits_le16_lanes", "visits_le8_lanes", "pairs_in_le16", "pairs_in_le8")
     return dict(zip(names, out.tolist()))
 
 

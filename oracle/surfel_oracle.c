@@ -1046,13 +1046,16 @@ void oracle_knn_queries(int P, const float *points, int nq, const int *queries, 
  *   out[8]  quadrant visits saved if two CONSECUTIVE blending entries of a tile whose masks are disjoint inside a
  *           quadrant shared one visit there (greedy pairing, back to front)
  *   out[9]  quadrant visits in which at most 32 lanes blend and they all sit in one half (top or bottom 8x4)
- *   out[10] quadrant visits in which the blending lanes sit in a single 16-lane row (8x2 pixels) */
-void oracle_lane_model(const OracleState *s, double *out /*11*/) {
+ *   out[10] quadrant visits in which the blending lanes sit in a single 16-lane row (8x2 pixels)
+ *   out[11] quadrant visits with at most 16 blending lanes, out[12] with at most 8 (gfx950 executes a VALU instruction
+ *           with <= 16 enabled lanes in a slow mode: profiles/r04_exec_lane_threshold.txt), out[13] / out[14] the
+ *           blending pixels in those visits */
+void oracle_lane_model(const OracleState *s, double *out /*15*/) {
     const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
-    double acc[11];
+    double acc[15];
     memset(acc, 0, sizeof acc);
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0, a9 = 0, a10 = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+:a0,a1,a2,a3,a4,a5,a6,a7,a8,a9,a10)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0, a9 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0, a14 = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+:a0,a1,a2,a3,a4,a5,a6,a7,a8,a9,a10,a11,a12,a13,a14)
     for (int tile = 0; tile < gx * gy; tile++) {
         int tx = tile % gx, ty = tile / gx;
         uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
@@ -1097,6 +1100,8 @@ void oracle_lane_model(const OracleState *s, double *out /*11*/) {
                 a3 += rowstrip[q]; a4 += colstrip[q];
                 if (quad[q] && quad[q] <= 32 && (top[q] == 0 || bot[q] == 0)) a9 += 1;
                 if (quad[q] && rows8x2[q][0] + rows8x2[q][1] + rows8x2[q][2] + rows8x2[q][3] == 1) a10 += 1;
+                if (quad[q] && quad[q] <= 16) { a11 += 1; a13 += quad[q]; }
+                if (quad[q] && quad[q] <= 8) { a12 += 1; a14 += quad[q]; }
             }
             a2 += nq;
             a5 += ntop > nbot ? ntop : nbot;
@@ -1128,7 +1133,7 @@ void oracle_lane_model(const OracleState *s, double *out /*11*/) {
         }
     }
     acc[0] = a0; acc[1] = a1; acc[2] = a2; acc[3] = a3; acc[4] = a4; acc[5] = a5; acc[6] = a6; acc[7] = a7; acc[8] = a8;
-    acc[9] = a9; acc[10] = a10;
+    acc[9] = a9; acc[10] = a10; acc[11] = a11; acc[12] = a12; acc[13] = a13; acc[14] = a14;
     memcpy(out, acc, sizeof acc);
 }
 

@@ -52,8 +52,12 @@ for v in views:
         extra_per_visit=0)
     row("perfect packing (lower bound: ceil(pixels / 64) per entry)", m["visits_lower_bound"], feasible=False)
     print(f"  quadrant visits whose blending lanes fit one 8x4 half: {100 * m['visits_in_one_half'] / m['visits_quadrants']:.1f} %, "
-          f"one 16-lane row (8x2): {100 * m['visits_in_one_row'] / m['visits_quadrants']:.1f} %  (worth something only if the SIMD "
-          f"skipped masked-off rows: tools/micro/valu_rate.hip measures that it does not / does)")
+          f"one 16-lane row (8x2): {100 * m['visits_in_one_row'] / m['visits_quadrants']:.1f} %  (worth nothing: the SIMD does not "
+          f"skip masked-off rows or halves, tools/micro/exec_rows.hip)")
+    print(f"  quadrant visits with <= 16 blending lanes: {100 * m['visits_le16_lanes'] / m['visits_quadrants']:.1f} % "
+          f"(they hold {100 * m['pairs_in_le16'] / pairs:.1f} % of the blending pixels), <= 8 lanes: "
+          f"{100 * m['visits_le8_lanes'] / m['visits_quadrants']:.1f} %  -- gfx950 runs a VALU instruction with <= 16 enabled lanes in a "
+          f"slow mode (profiles/r04_exec_lane_threshold.txt)")
 print("""
 note: a lane's per-pixel state (T, the two recurrences, nine cotangents: 12 registers per pixel, 4 pixels per lane) is
 addressed by STATIC register names; a visit in which the two half-waves (or the four rows) work on different quadrants
