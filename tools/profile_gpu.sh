@@ -11,7 +11,7 @@ OUT=/tmp/prof_$TAG
 KEEP=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $KEEP
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+BENCH="python $REPO/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --views-in-flight 0 --sustained-seconds 0.2"
 # kernel trace + stats of the command the driver runs (default steps / warm-up, sustained pass included) minus two legs: the
 # CPU baseline launches no kernels, and the views-in-flight leg runs K steps CONCURRENTLY on K streams -- its kernels overlap
 # and would inflate every per-kernel average (preprocess_bwd 0.20 -> 0.36 ms) without being part of the headline
