@@ -52,7 +52,6 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024           # 256 CUs x 4 SIMDs
-FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 STRONG_VIEWS = 8       # C4 = 8 training views per optimiser step over 1/2/4/8 GPUs
 
 
@@ -659,35 +658,39 @@ def main():
         if pk and "SQ_INSTS_VALU" in pk:
             insts = float(pk["SQ_INSTS_VALU"])
             t = kernels_ms[dom] * 1e-3
-            # Calibration (tools/micro/valu_rate.hip, profiles/r03_valu_rate.txt): a wave64 VALU instruction holds its
-            # SIMD for 4 cycles (v_fma/mul/mov_f32; packed FP32 ~5, transcendentals ~6-9), an instruction issued under
-            # an empty EXEC mask retires in ~1.  `cycles_per_instruction_profiled` is the launch's own quotient --
-            # SIMD cycles (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) / counted instructions -- so nothing is assumed
-            # about the clock; at or below ~4.2 the SIMDs do nothing but issue VALU instructions.
+            # Calibration (tools/micro/exec_rows.hip, profiles/r04_exec_lane_threshold.txt; long kernels -- round 3's "4 cycles"
+            # carried ~86 us of per-launch start-up): at 4 waves per SIMD independent v_fma_f32 issue at 2.77 nominal cycles
+            # per wave instruction (2.0 = the part's 157 TFLOP/s), a transcendental costs ~13.5, and ONE wave issues a
+            # DEPENDENT instruction every ~21 cycles -- four waves of dependent code reach 5.3 cycles per instruction.
+            # `cycles_per_instruction_profiled` is the launch's own quotient -- SIMD cycles (GRBM_GUI_ACTIVE / 8 XCDs x 1024
+            # SIMDs) / counted VALU instructions -- so nothing is assumed about the clock.  The blend kernels sit between the
+            # two: bound by how fast four (seven) waves of mostly dependent code can issue, scalar instructions and branches
+            # included, not by the FMA rate.
             cpi = (pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS / insts) if pk.get("GRBM_GUI_ACTIVE") else None
-            issue = round(min(1.0, 4.0 / cpi), 4) if cpi else None
-            # how much of that issue rate does arithmetic on live pixels: lanes with a contributing pixel / 64 per
-            # VALU instruction of the entry loop (profiles/r04_lane_util_model.txt, measured on recorded S3 frames), and
-            # the part's FP32 rate counts an FMA on all 64 lanes every 4 cycles as 128 flop
+            FMA_CPI, DEP_CPI_4WAVES = 2.77, 5.3
+            issue = round(min(1.0, FMA_CPI / cpi), 4) if cpi else None
+            # how much of that issue rate does arithmetic on live pixels: lanes with a blending pixel / 64 per visit of the
+            # entry loop (profiles/r04_lane_util_model.txt, the oracle's exact `act` predicate on real S3 frames)
             lane = (pmc or {}).get("useful_lane_frac", {}).get(dom)
             valu = {"wave_instructions_per_launch": int(insts),
                     "cycles_per_instruction_profiled": round(cpi, 3) if cpi else None,
-                    "full_rate_cycles_per_instruction": 4.0,
-                    # share of the SIMDs' issue slots the launch used, clock-free: 1.0 when cpi <= 4
+                    "full_rate_cycles_per_instruction": FMA_CPI,
+                    "dependent_code_cycles_per_instruction_at_4_waves": DEP_CPI_4WAVES,
+                    # share of the SIMDs' FMA issue rate the launch used, clock-free
                     "simd_issue_utilisation": issue,
                     "frac_of_scalar_issue": issue,
                     "useful_lane_frac": lane,
-                    # instructions x 64 lanes x useful share, as a fraction of lanes x cycles the launch had: what is
-                    # left of the FP32 peak if every instruction were an FMA (an upper bound: many are not)
-                    "frac_of_fp32_peak": (round(issue * lane, 4) if (issue is not None and lane is not None) else None),
+                    # issue share x useful lanes x (2.0 / 2.77: what independent FMAs reach of the 157 TFLOP/s): an upper
+                    # bound of the FP32 peak fraction (it counts every instruction as an FMA)
+                    "frac_of_fp32_peak": (round(issue * lane * 2.0 / FMA_CPI, 4) if (issue is not None and lane is not None) else None),
                     "ns_per_instruction_this_run": round(t * SIMDS / insts * 1e9, 4),
-                    "microbenchmark_ns_per_v_fma_f32": [1.73, 1.97],
-                    "calibration": "tools/micro/valu_rate.hip on MI355X (profiles/r03_valu_rate.txt): back-to-back "
-                                   "v_fma_f32 1.73-1.97 ns per wave instruction and SIMD (4 cycles at the clock the part "
-                                   "sustains under that load), v_pk_fma_f32 2.45 ns"}
+                    "calibration": "tools/micro/exec_rows.hip on MI355X (profiles/r04_exec_lane_threshold.txt): independent "
+                                   "v_fma_f32 2.77 cycles per wave instruction at 4 waves per SIMD, the blend mix (6 fma + exp + "
+                                   "rcp) 5.46, one dependent chain per wave 5.3"}
         if valu and valu["simd_issue_utilisation"] is not None:
             # the roof the kernel is closer to -- or neither: a small frame (S1: one wave per SIMD) runs at a third of
             # the issue rate and 2 % of the HBM peak; that is latency, not a roofline
+            # "valu" = instruction issue / latency of the waves' own code (see `valu`), as opposed to memory
             bound = "valu" if valu["simd_issue_utilisation"] > achieved / HBM_PEAK_GBS else "hbm"
             if max(valu["simd_issue_utilisation"], achieved / HBM_PEAK_GBS) < 0.5:
                 bound = "latency"
