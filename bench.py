@@ -608,6 +608,8 @@ def main():
                     "visible-rows all-reduce: MAX all-reduce of the radii + one SUM all-reduce of the union's rows"),
             "why": exchange_why,
             "coalesced_gather": bool(getattr(reducer, "_coalesce", False)) if exchange == "owner" else None,
+            # dense: every owner's whole shard; sparse: only the rows some rank saw (a minority of the scene on few ranks)
+            "gather": getattr(reducer, "last_gather", None) if exchange == "owner" else None,
             "ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None,
             "ms_pieces": exchange_pieces,
             "pieces_note": ("HIP-event pairs on rank 0 in the instrumented pass; begin_local + max_all_reduce are issued "

@@ -125,7 +125,8 @@ class OwnerReduce:
       begin(visible, radii)  right after the forward (the radii are known): the indices of this rank's visible rows
                        (fixed-size list, no host wait), their per-owner counts (two binary searches per owner), and
                        ONE all-reduce(MAX) over an int32 buffer [P + world^2] that carries the radii (-> max_radii2D,
-                       train_with_refine_depth.py:583) AND the count matrix (rank r fills row r, everything else is
+                       train_with_refine_depth.py:583; bit 30 of a row = "visible on this rank", so the MAX also yields
+                       the union of the visible sets) AND the count matrix (rank r fills row r, everything else is
                        zero, so MAX is a gather); the matrix tail goes to pinned host memory asynchronously.  All of
                        it overlaps the backward: the sizes are on the host long before they are needed.
       finish()         after the backward: ONE g4s_pack_rows launch packs this rank's visible rows row-major with their
@@ -135,7 +136,10 @@ class OwnerReduce:
                        indices read from the buffer); then (gather=True) the reduced shards are all-gathered IN
                        PLACE, one collective per tensor issued as one RCCL group, straight into the gradient tensors --
                        rank d's rows of a contiguous [P, w] tensor are contiguous.  (P not divisible by the world
-                       size: ragged shards go through a padded staging buffer.)  finish(gather=False) stops after
+                       size: ragged shards go through a padded staging buffer.)  When the rows visible on SOME rank are
+                       fewer than `sparse_below` x P (known from begin()'s MAX-reduced radii, identically on every
+                       rank), only those rows are gathered: owners pack them, ONE all_gather of equally padded
+                       shards, every rank unpacks (`last_gather` says which form ran).  finish(gather=False) stops after
                        the owner's accumulation: ShardedAdam (below) then steps the owner's shard and gathers
                        PARAMETERS instead of gradients.
 
@@ -171,6 +175,12 @@ class OwnerReduce:
             # ---- persistent state (LAB_NOTES.md: collectives on persistent buffers only)
             self._meta = torch.zeros(self.P + W2, dtype=torch.int32, device=dev)  # radii | count matrix [src, dst]
             self._max_radii = torch.zeros(self.P, dtype=torch.int32, device=dev)  # what max_radii returns
+            # sparse gather of the reduced shards (rows visible on SOME rank only): union mask / index list / per-owner counts
+            self._union = torch.zeros(self.P, dtype=torch.bool, device=dev)
+            self._uidx = torch.empty(self.P, dtype=torch.int64, device=dev)
+            self._ucounts_host = (torch.zeros(self.world, dtype=torch.int32).pin_memory() if self.hip
+                                  else torch.zeros(self.world, dtype=torch.int32))
+            self._gin = self._gout = None  # float32 [capacity, width], grown on demand
             self._ragged_stage = {}  # (dtype, width) -> (stage, mine): all_gather_rows with ragged shards
             self._idx = torch.empty(self.P, dtype=torch.int64, device=dev)
             self._edges = torch.tensor([min(d * self.shard, self.P) for d in range(self.world + 1)], dtype=torch.int64,
@@ -184,6 +194,11 @@ class OwnerReduce:
                 self._gather = torch.zeros(self.world * self.shard, self.width, device=dev)
                 self._acc = torch.zeros(self.shard, self.width, device=dev)
         self._pending = False
+        self._have_union = False
+        # Gather only the rows some rank saw when they are a minority (sparse_below x P): on 2 / 4 ranks the union of the
+        # step's views is 39 % / 70 % of S3's rows and ONE / three xGMI links carry a whole shard per step otherwise.
+        self.sparse_below = 0.6
+        self.last_gather = None  # "dense" | "sparse": what the last finish(gather=True) did
         self._nonzero_static = hasattr(torch, "nonzero_static")
         # one RCCL group call for the per-tensor in-place gathers: probed ONCE, on a dummy tensor, and agreed on by all
         # ranks -- a rank that fell back on its own would issue a different collective sequence from its peers
@@ -281,10 +296,14 @@ class OwnerReduce:
             # scatter_add of 1.5 M ones onto 8 counters would serialise on them)
             pos = torch.searchsorted(self._idx, self._edges)
             meta = self._meta
+            # per row: the radius in the low 30 bits and "visible on this rank" in bit 30 -- after the MAX, bit 30 is the
+            # union of the ranks' visible sets whatever the radii are, and the low bits are the largest radius among the
+            # ranks that see the row (the others hold 0)
             if radii is not None:
                 meta[:self.P].copy_(radii)
+                meta[:self.P].bitwise_or_(visible.to(torch.int32) << 30)
             else:
-                meta[:self.P].zero_()
+                torch.mul(visible.to(torch.int32), 1 << 30, out=meta[:self.P])
             tail = meta[self.P:].view(self.world, self.world)
             tail.zero_()
             tail[self.rank].copy_(pos[1:] - pos[:-1])
@@ -292,6 +311,24 @@ class OwnerReduce:
             with self._timed("max_all_reduce"):
                 dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=self.group)  # radii MAX + the count matrix, one collective
             self.last_bytes["max_all_reduce"] = int(meta.numel() * 4 * 2 * (self.world - 1) / max(self.world, 1))
+            # the union of the ranks' visible sets (every rank computes the same list from the same reduced radii) and
+            # its per-owner counts, for the sparse gather of finish(); sizes reach the host with the count matrix
+            self._have_union = self.world > 1
+            if self._have_union:
+                with self._timed("begin_union"):
+                    torch.ge(meta[:self.P], 1 << 30, out=self._union)
+                    if self._nonzero_static:
+                        try:
+                            torch.nonzero_static(self._union, size=self.P, fill_value=self.P, out=self._uidx.view(self.P, 1))
+                        except (TypeError, RuntimeError):
+                            self._uidx.copy_(torch.nonzero_static(self._union, size=self.P, fill_value=self.P).view(-1))
+                    else:
+                        nz = self._union.nonzero(as_tuple=True)[0]
+                        self._uidx.fill_(self.P)
+                        self._uidx[:nz.numel()] = nz
+                    upos = torch.searchsorted(self._uidx, self._edges)
+                    self._ucounts_dev = (upos[1:] - upos[:-1]).to(torch.int32)
+                    self._ucounts_host.copy_(self._ucounts_dev, non_blocking=self.hip)
             if self.hip:
                 self._counts_host.copy_(meta[self.P:], non_blocking=True)
                 self._event.record(torch.cuda.current_stream(self.dev))
@@ -355,7 +392,7 @@ class OwnerReduce:
         self._pending = False
         if self._event is not None:
             self._event.synchronize()  # recorded a whole backward ago: returns at once
-        self._max_radii.copy_(self._meta[:self.P])  # (the next begin() reuses _meta)
+        torch.bitwise_and(self._meta[:self.P], (1 << 30) - 1, out=self._max_radii)  # (the next begin() reuses _meta)
         mat = self._counts_host.view(self.world, self.world).tolist()
         send = [int(x) for x in mat[self.rank]]
         recv = [int(mat[s][self.rank]) for s in range(self.world)]
@@ -410,6 +447,12 @@ class OwnerReduce:
                 return
             # every rank gets every reduced shard
             lo, hi = self.bounds()
+            if self._have_union:
+                cu = [int(x) for x in self._ucounts_host.tolist()]
+                if sum(cu) < self.sparse_below * self.P:
+                    self._sparse_gather(cu)
+                    return
+            self.last_gather = "dense"
             self.last_bytes["all_gather_sent_per_peer"] = (hi - lo) * W * 4
             self.last_bytes["all_gather_received"] = (self.P - (hi - lo)) * W * 4
             if self.even:
@@ -428,6 +471,57 @@ class OwnerReduce:
                 for r, w in zip(self.rows, self.widths):
                     r.copy_(full[:, off:off + w])
                     off += w
+
+
+    def _sparse_gather(self, cu):
+        """Gather of the reduced shards restricted to the rows some rank saw (`cu[d]` of them in owner d's shard, the
+        same numbers and the same index list `_uidx` on every rank): owner d packs ITS union rows, one all_gather of
+        shards padded to the largest count moves them, every rank writes the other owners' rows where they belong.
+        Rows outside the union are zero on every rank and stay so.  Bit-identical to the dense gather."""
+        W = self.width
+        me = self.rank
+        maxc = max(cu)
+        offs = [0]
+        for c in cu:
+            offs.append(offs[-1] + c)
+        self.last_gather = "sparse"
+        self.last_bytes["all_gather_sent_per_peer"] = maxc * W * 4
+        self.last_bytes["all_gather_received"] = (self.world - 1) * maxc * W * 4
+        if maxc == 0:
+            return
+
+        def grow(name, rows):
+            buf = getattr(self, name)
+            if buf is None or buf.shape[0] < rows:
+                buf = torch.empty(max(int(rows * 1.25) + 1024, 0 if buf is None else buf.shape[0]), W, device=self.dev)
+                setattr(self, name, buf)
+                self.allocations += 1
+            return buf
+        gin = grow("_gin", maxc)[:maxc]
+        gout = grow("_gout", self.world * maxc)[:self.world * maxc]
+        with self._timed("all_gather"):
+            mine = self._uidx[offs[me]:offs[me] + cu[me]]
+            if self.hip:
+                if cu[me]:
+                    self._rows_kernel(mine, cu[me], gin, 2)          # pack, row-major
+            else:
+                off = 0
+                for r, w in zip(self.rows, self.widths):
+                    gin[:cu[me], off:off + w] = r.index_select(0, mine)
+                    off += w
+            dist.all_gather_into_tensor(gout.view(-1), gin.view(-1), group=self.group)
+            for s_ in range(self.world):
+                if s_ == me or cu[s_] == 0:
+                    continue
+                idx = self._uidx[offs[s_]:offs[s_] + cu[s_]]
+                part = gout[s_ * maxc:s_ * maxc + cu[s_]]
+                if self.hip:
+                    self._rows_kernel(idx, cu[s_], part, 3)          # unpack, row-major, overwrite
+                else:
+                    off = 0
+                    for r, w in zip(self.rows, self.widths):
+                        r.index_copy_(0, idx, part[:, off:off + w])
+                        off += w
 
 
 class _nullctx:
