@@ -41,7 +41,7 @@ for v in views:
         return _C.rasterize_gaussians_backward(bg, d["means3D"], f[3], e, d["scales"], d["rotations"], 1.0, e, c["view"], c["proj"],
                                                c["tanfovx"], c["tanfovy"], gc, go, d["sh"], D, c["campos"], f[4], f[0], f[5], f[6], False)
 
-    for thr in (None, 3000, 2000, 1500, 1200, 1000, 800, 600, 400):
+    for thr in (None, 3000, 2000, 1500, 1200, 1000, 800, 600, 400, -1):
         ctx = _lib.option("bwd_hot_threshold", thr) if thr is not None else None
         if ctx:
             ctx.__enter__()
@@ -55,5 +55,5 @@ for v in views:
         ms = (time.perf_counter() - t0) / 20 * 1e3
         if ctx:
             ctx.__exit__(None, None, None)
-        hot = int((n_live > (thr if thr is not None else max(4 * int(f[0]) // len(n_live), 2048))).sum())
+        hot = len(n_live) if thr == -1 else int((n_live > (thr if thr is not None else max(4 * int(f[0]) // len(n_live), 2048))).sum())
         print(f"   threshold {str(thr):>5s}: backward {ms:.3f} ms  ({hot} tiles to the four-wave kernel)")
