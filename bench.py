@@ -243,16 +243,14 @@ def main():
             return [(rank + j * world) % len(dcams) for j in range(views_per_rank)]
         return [(rank + i * world) % len(dcams)]
 
-    def exchange_step(radii, gm2):
-        """weak scaling: statistics of the one view, then the collectives (the owner exchange's begin() has been issued
-        right after the forward)."""
+    def exchange_step(radii):
+        """weak scaling: the collectives (the owner exchange's begin() has been issued right after the forward; the view's
+        statistics were written into `side` by the backward)."""
         nonlocal exchange_events
         ev = None
         if exchange_events is not None:  # instrumented pass only: GPU time of the exchange, this rank
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        torch.linalg.vector_norm(gm2[:, :2], dim=1, out=side[:, 0])
-        side[:, 1] = radii > 0
         if exchange == "owner":
             reducer.finish()  # (reducer.max_radii = MAX over the ranks of the radii, from begin()'s collective)
             exchanged_rows.append(reducer.last_rows_sent)
@@ -280,12 +278,18 @@ def main():
         if dist is not None and exchange == "owner":
             # sizes travel to the host while the backward runs; the radii MAX (-> max_radii2D) rides in the same collective
             reducer.begin(radii > 0, radii=radii)
-        grads = _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
-                                                1.0, empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"],
-                                                dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
-                                                img, False, out=grad_out)
+        out = grad_out
         if dist is not None:
-            exchange_step(radii, grads[0])
+            # the densification statistics of the view (||dL_dmeans2D.xy||, visible) come out of the per-Gaussian kernel
+            # itself (g4s_rasterizer_backward_accumulate, first_view: every row written like the plain call): no torch
+            # kernels between the backward and the exchange
+            out = dict(grad_out, accumulate="first", view_stats=side)
+        _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
+                                        1.0, empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"],
+                                        dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
+                                        img, False, out=out)
+        if dist is not None:
+            exchange_step(radii)
         return [(R, radii)]
 
     def step_strong(i):
