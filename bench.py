@@ -141,6 +141,13 @@ def summarize_steps(per_step_ms, mean_ms):
             "disturbed_steps": [i for i, t in enumerate(per_step_ms) if t > 1.5 * med] if disturbed else []}
 
 
+def pick_headline(attempts):
+    """The pass the line reports: the median (by mean step time) of the undisturbed passes -- of all passes if none was
+    clean, in which case the chosen pass itself says `disturbed`."""
+    clean = [a for a in attempts if not a["disturbed"]] or attempts
+    return sorted(clean, key=lambda a: a["mean_ms"])[(len(clean) - 1) // 2]
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -514,8 +521,7 @@ def main():
         attempts.append(summ)
         if sum(1 for a in attempts if not a["disturbed"]) >= 3:
             break
-    clean = [a for a in attempts if not a["disturbed"]] or attempts
-    head = sorted(clean, key=lambda a: a["mean_ms"])[(len(clean) - 1) // 2]
+    head = pick_headline(attempts)
     mem1 = torch.cuda.memory_stats(device)
 
     # Sustained throughput: the same step, issued back to back right behind the headline pass (no pause anywhere), for
