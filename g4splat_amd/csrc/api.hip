@@ -307,6 +307,7 @@ static int rasterizer_forward_impl(
         pa.scale_modifier = scale_modifier;
         pa.shs_rest = shs_rest;
         pa.sh_vec16 = (shs != nullptr && shs_rest == nullptr && M == 16 && !misaligned(shs, 16));
+        pa.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
         pa.tight_rect = (uint2*)(geom + GL.tight_rect);
         pa.depth_keys = keys_a;
@@ -432,7 +433,6 @@ static int rasterizer_forward_impl(
     ba.final_T = final_T; ba.n_contrib = n_contrib; ba.out_color = out_color; ba.out_others = out_others;
     ba.qhit = qhit_ptr;
     ba.box_only = opt(OPT_BOX_ONLY) != 0;
-    ba.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
     { ProfScope ps(PF_BLEND_FWD, stream); launch_blend_fwd(ba, stream); }
     CHECK_LAUNCH("blend_fwd");
     return R;
@@ -504,7 +504,6 @@ static int rasterizer_backward_impl(
     float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
     float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream_, bool accumulate = false,
     void* after_event = nullptr, float* view_stats = nullptr) {
-    (void)scale_modifier;
     hipStream_t stream = (hipStream_t)stream_;
     t_err[0] = 0;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "bad sizes");
@@ -559,7 +558,6 @@ static int rasterizer_backward_impl(
         bb.qhit = (const uint8_t*)(bin + BL.qhit);
         bb.dL_dpix = dL_dpix; bb.dL_depths = dL_depths; bb.grad_inst = grad_inst; bb.rec_flag = rec_flag;
         bb.n_slots = (uint32_t)R;
-        bb.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
         // One wave per tile is the efficient form when there are enough tiles to fill the GPU (1 024 SIMDs x 3
         // waves); a small frame (<= 768 tiles, e.g. 256 x 256) runs about twice as fast with four waves per tile,
         // and so does any single tile that is much deeper than the rest (measured: tools/deep_tile_bench.py).
@@ -604,6 +602,8 @@ static int rasterizer_backward_impl(
     pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = campos;
     pb.radii = radii; pb.rec = rec; pb.clamped = (const uint8_t*)(geom + GL.clamped); pb.grad_inst = grad_inst;
     pb.rec_flag = rec_flag; pb.n_slots = (uint32_t)R;
+    // the forward's own T (scale_modifier applied, exact W / H) is what the blend kernels' moments refer to
+    pb.frame_W = width; pb.frame_H = height; pb.scale_modifier = scale_modifier;
     pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest; pb.sh_prezeroed = sh_prezeroed;
     pb.accumulate = accumulate;
     pb.view_stats = view_stats;

@@ -25,9 +25,11 @@
 
 namespace g4s {
 
-// true if the 8x8 pixel quadrant [qx, qx+7] x [qy, qy+7] misses the splat's alpha-cutoff box
-__device__ __forceinline__ bool quad_misses_box(const float4 box, float qx, float qy) {
-    return box.x > qx + 7.0f || box.z < qx || box.y > qy + 7.0f || box.w < qy;
+// true if the 8x8 pixel quadrant (kx, ky) -- pixels [8 kx, 8 kx + 7] x [8 ky, 8 ky + 7] -- misses the splat's alpha-cutoff
+// box (record quad 5: quadrant bounds, g4s_internal.h)
+__device__ __forceinline__ bool quad_misses_box(const float4 q5, uint32_t kx, uint32_t ky) {
+    const uint32_t x0 = __float_as_uint(q5.x), x1 = __float_as_uint(q5.y), yw = __float_as_uint(q5.w);
+    return kx < x0 || kx > x1 || ky < (yw & 0xFFFFu) || ky > (yw >> 16);
 }
 
 // true if no pixel of the quadrant can pass the alpha test: the quadrant rectangle [qx, qx+7] x [qy, qy+7] meets
@@ -76,7 +78,7 @@ struct FwdPixel {
 constexpr float FWD_MSCALE = FAR_N / (FAR_N - NEAR_N);
 constexpr float FWD_DMD_K = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m(depth) = mscale - dmd_k / depth
 
-// one pixel against one staged splat (forward.cu:349-433).  `nolp` is wave-uniform (see eval_pair).
+// one pixel against one staged splat (forward.cu:349-433).  `nolp` (wave-uniform) = the splat is REC_AFFINE (see eval_pair).
 __device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, float pyf, const float4 q0, const float4 q1,
                                           const float4 q2, const float4 q3, const float4 q4, uint32_t contributor) {
     PairEval e;
@@ -90,7 +92,7 @@ __device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, flo
         } else {
             const float w = alpha * T;
             const float A = 1 - T;
-            const float md = fmaf(-FWD_DMD_K, __builtin_amdgcn_rcpf(depth), FWD_MSCALE);
+            const float md = fmaf(-FWD_DMD_K, e.inv_depth, FWD_MSCALE);  // 1 / depth = p'.z: no second reciprocal
             const float md2 = md * md;
             p.distortion = fmaf(fmaf(-(md + md), p.M1, fmaf(md2, A, p.M2)), w, p.distortion);
             p.Dd = fmaf(depth, w, p.Dd);
@@ -154,13 +156,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
             uint32_t relmask = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float bx = (float)(tile_x * TILE + (q & 1) * 8), by = (float)(tile_y * TILE + (q >> 1) * 8);
-                bool rel = !quad_misses_box(rq[5], bx, by);
-                if (rel && !a.box_only) rel = !quad_misses_region(rq[0], rq[6], rq[7], bx, by);
+                const int bxi = tile_x * TILE + (q & 1) * 8, byi = tile_y * TILE + (q >> 1) * 8;
+                bool rel = !quad_misses_box(rq[5], (uint32_t)(bxi >> 3), (uint32_t)(byi >> 3));
+                if (rel && !a.box_only) rel = !quad_misses_region(rq[0], rq[6], rq[7], (float)bxi, (float)byi);
                 relmask |= rel ? (1u << q) : 0u;
             }
-            // bit 4: this splat's record says the low-pass exponent never matters (eval_pair's nolp)
-            if (!a.no_fastpath && (__float_as_uint(rq[0].w) & REC_NO_LOWPASS)) relmask |= 16u;
+            // bit 4: quads 2..4 of this splat's record hold the affine form of the ray-splat intersection (REC_AFFINE)
+            if (__float_as_uint(rq[0].w) & REC_AFFINE) relmask |= 16u;
             s_rel[threadIdx.x] = relmask;
         }
         if (threadIdx.x < (FWD_BATCH / 64) * 4) (&s_hit[0][0])[threadIdx.x] = 0ull;
@@ -370,7 +372,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) rq[i] = r[i];  // all loads in flight before any LDS store
             const float4 q0 = rq[0];
-            nolp_l = !a.no_fastpath && (__float_as_uint(q0.w) & REC_NO_LOWPASS) != 0;
+            nolp_l = (__float_as_uint(q0.w) & REC_AFFINE) != 0;
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
             // (the rect's origin word sits in q7.w, in the 64-byte line q4 was just read from)
@@ -380,26 +382,29 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
         __syncthreads();
 
         uint64_t todo = __ballot(qmask != 0);
-        const uint64_t nolp_mask = __ballot(nolp_l);  // wave-uniform: entries whose low-pass exponent never matters
+        const uint64_t nolp_mask = __ballot(nolp_l);  // wave-uniform: REC_AFFINE entries
         while (todo) {
             const int j = (int)__builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)qmask, j);  // wave-uniform
             const bool nolp = (nolp_mask >> j) & 1ull;                               // scalar
+            // == !nolp, in an SGPR and opaque to the optimiser (see the gradient block)
+            const uint32_t general = (uint32_t)__builtin_amdgcn_readfirstlane(nolp ? 0 : 1);
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-            // the 18 accumulators are plain floats zeroed one by one, and the zero is pinned here: left alone, the
+            // the accumulators are plain floats zeroed one by one, and the zero is pinned here: left alone, the
             // compiler sinks the initialisation into both arms of the first quadrant's branch and joins them with a
             // 16-deep copy chain (33 moves).  (Nine 64-bit register pairs zeroed with v_mov_b64 looked cheaper but every
             // half had to be copied out again in front of the permlane swaps of the reduction: 9 + 15 moves instead of 18.)
-            struct F2 { float x, y; };
-            F2 gp[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                gp[i].x = 0.0f;
-                gp[i].y = 0.0f;
-                asm volatile("" : "+v"(gp[i].x), "+v"(gp[i].y));
-            }
+            // record order (g4s_internal.h): gc* colour, gn* normal, gt0..gt8 the T terms (moments S, X, Y of dL/dp' for a
+            // REC_AFFINE splat, dL/dTu, dL/dTv, dL/dTw otherwise), gop opacity; glp* = the low-pass branch's centre terms.
+            // Separate scalars, not an array: an array handed to the reduction by reference becomes one 512-bit register
+            // tuple, and every arm of the branches below then ends in a copy of all sixteen registers.
+            float gc0 = 0.0f, gc1 = 0.0f, gc2 = 0.0f, gn0 = 0.0f, gn1 = 0.0f, gn2 = 0.0f, gt0 = 0.0f, gt1 = 0.0f, gt2 = 0.0f, gt3 = 0.0f,
+                  gt4 = 0.0f, gt5 = 0.0f, gt6 = 0.0f, gt7 = 0.0f, gt8 = 0.0f, gop = 0.0f, glp0 = 0.0f, glp1 = 0.0f;
+            asm volatile("" : "+v"(gc0), "+v"(gc1), "+v"(gc2), "+v"(gn0), "+v"(gn1), "+v"(gn2));
+            asm volatile("" : "+v"(gt0), "+v"(gt1), "+v"(gt2), "+v"(gt3), "+v"(gt4), "+v"(gt5), "+v"(gt6), "+v"(gt7), "+v"(gt8));
+            asm volatile("" : "+v"(gop), "+v"(glp0), "+v"(glp1));
             bool lowpass = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -432,14 +437,14 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                     const float v_minus_rec = v - x.V_rec;
                     float dL_dalpha = v_minus_rec;
                     x.V_rec = fmaf(alpha, v_minus_rec, x.V_rec);
-                    gp[0].x = fmaf(w, x.dpx0, gp[0].x);
-                    gp[0].y = fmaf(w, x.dpx1, gp[0].y);
-                    gp[1].x = fmaf(w, x.dpx2, gp[1].x);
-                    gp[1].y = fmaf(w, x.dn0, gp[1].y);
-                    gp[2].x = fmaf(w, x.dn1, gp[2].x);
-                    gp[2].y = fmaf(w, x.dn2, gp[2].y);
+                    gc0 = fmaf(w, x.dpx0, gc0);
+                    gc1 = fmaf(w, x.dpx1, gc1);
+                    gc2 = fmaf(w, x.dpx2, gc2);
+                    gn0 = fmaf(w, x.dn0, gn0);
+                    gn1 = fmaf(w, x.dn1, gn1);
+                    gn2 = fmaf(w, x.dn2, gn2);
 
-                    const float inv_cd = fast_rcp(c_d);
+                    const float inv_cd = e.inv_depth;  // = p'.z on the fast path: no reciprocal
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
                     float dL_dz = 0.0f;
@@ -456,55 +461,82 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                     const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
 
-                    if (e.in3d) {
+                    if (nolp) {  // scalar branch: REC_AFFINE splat (always in3d)
+                        // backward.cu:396-426 in the affine form: G = exp(-|s|^2 / 2), s = p'.xy / p'.z, depth = 1 / p'.z
+                        //   dL/dp'.xy = dL/ds / p'.z,   dL/dp'.z = -(s . dL/ds + depth dL/ddepth) / p'.z
+                        // and the only thing accumulated for T are the moments S, X, Y of dL/dp' (the reference's dL/dk =
+                        // l x dL/dp, dL/dl = dL/dp x k and its 18 accumulations per pixel are linear in the pixel: K8 takes
+                        // the cross products once per Gaussian)
+                        const float mGi = (dL_dG * -G) * e.inv_pz;
+                        const float dpx_ = mGi * e.sx, dpy_ = mGi * e.sy;
+                        const float ndpz = fmaf(dpx_, e.sx, fmaf(dpy_, e.sy, (dL_dz * e.inv_pz) * e.inv_pz));  // -dL/dp'.z (depth = 1 / p'.z)
+                        acc_add(gt0, dpx_);  // (in place: see acc_fma)
+                        acc_add(gt1, dpy_);
+                        acc_sub(gt2, ndpz);
+                        acc_fma(gt3, e.dx, dpx_);
+                        acc_fma(gt4, e.dx, dpy_);
+                        acc_fnma(gt5, e.dx, ndpz);
+                        acc_fma(gt6, e.dy, dpx_);
+                        acc_fma(gt7, e.dy, dpy_);
+                        acc_fnma(gt8, e.dy, ndpz);
+                    }
+                    // (two regions in a row on two conditions the compiler cannot relate, not if / else: under one uniform
+                    // test the divergent branch below makes hipcc structurize the whole nest with flag registers and copy
+                    // the accumulators in and out of the arm above)
+                    if (general) {
+                    if (e.in3d) {  // general path, backward.cu:396-426 as written: gt0..gt8 = dL/dTu, dL/dTv, dL/dTw
                         const float mG = dL_dG * -G;
                         const float dL_dsx = fmaf(mG, e.sx, dL_dz * q3.z);
                         const float dL_dsy = fmaf(mG, e.sy, dL_dz * q3.w);
                         const float inv_pz = e.inv_pz;  // the v_rcp_f32 of eval_pair
                         const float dpx_ = dL_dsx * inv_pz, dpy_ = dL_dsy * inv_pz;
                         const float dpz_ = -fmaf(dpx_, e.sx, dpy_ * e.sy);
-                        // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k)
-                        const float dkx = fmaf(e.ly, dpz_, -(e.lz * dpy_)), dky = fmaf(e.lz, dpx_, -(e.lx * dpz_)),
-                                    dkz = fmaf(e.lx, dpy_, -(e.ly * dpx_));
-                        const float dlx = fmaf(dpy_, e.kz, -(dpz_ * e.ky)), dly = fmaf(dpz_, e.kx, -(dpx_ * e.kz)),
-                                    dlz = fmaf(dpx_, e.ky, -(dpy_ * e.kx));
-                        gp[3].x -= dkx;
-                        gp[3].y -= dky;
-                        gp[4].x -= dkz;
-                        gp[4].y -= dlx;
-                        gp[5].x -= dly;
-                        gp[5].y -= dlz;
-                        gp[6].x += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
-                        gp[6].y += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
-                        gp[7].x += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
+                        // dL_dk = cross(l, dL_dp), dL_dl = cross(dL_dp, k); k and l are formed again here (bit-identical to
+                        // eval_pair's) rather than carried across the visit: six registers the affine path never needs
+                        const float kx = fmaf(pxf, q3.z, -q2.x), ky = fmaf(pxf, q3.w, -q2.y), kz = fmaf(pxf, q4.x, -q2.z);
+                        const float lx = fmaf(pyf, q3.z, -q2.w), ly = fmaf(pyf, q3.w, -q3.x), lz = fmaf(pyf, q4.x, -q3.y);
+                        const float dkx = fmaf(ly, dpz_, -(lz * dpy_)), dky = fmaf(lz, dpx_, -(lx * dpz_)),
+                                    dkz = fmaf(lx, dpy_, -(ly * dpx_));
+                        const float dlx = fmaf(dpy_, kz, -(dpz_ * ky)), dly = fmaf(dpz_, kx, -(dpx_ * kz)),
+                                    dlz = fmaf(dpx_, ky, -(dpy_ * kx));
+                        gt0 -= dkx;
+                        gt1 -= dky;
+                        gt2 -= dkz;
+                        gt3 -= dlx;
+                        gt4 -= dly;
+                        gt5 -= dlz;
+                        gt6 += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
+                        gt7 += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
+                        gt8 += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
                     } else {
-                        const float c2 = dL_dG * (-G * FILTER_INV_SQUARE);
-                        gp[7].y = fmaf(c2, e.dx, gp[7].y);
-                        gp[8].x = fmaf(c2, e.dy, gp[8].x);
-                        gp[7].x += dL_dz;
+                        // backward.cu:427-434 (d = centre - pixel = -e.dx)
+                        const float c2 = dL_dG * (G * FILTER_INV_SQUARE);
+                        glp0 = fmaf(c2, e.dx, glp0);
+                        glp1 = fmaf(c2, e.dy, glp1);
+                        gt8 += dL_dz;  // depth = Tw.z here, and on the general path term 14 is dL/dTw.z
                         lowpass = true;
                     }
-                    gp[8].y = fmaf(G, dL_dalpha, gp[8].y);
+                    }
+                    gop = fmaf(G, dL_dalpha, gop);
                 }
             }
             // 256 pixels -> 1: the four pixels of a lane were summed in registers above; the 64 lanes are
             // summed sixteen terms at a time, after which row k holds terms 4k..4k+3 and its last lane writes
             // them with one 16-byte store.
-            // Record layout: floats 0..14 = terms 0..14 (colour, normal, T), 15 = opacity term, 16..17 = the
-            // low-pass centre terms -- those are non-zero only when some pixel took the 2-D filter branch
-            // (rare for splats wider than a pixel), so their group is reduced and stored only then.  The record
+            // Record layout (g4s_internal.h): floats 0..14 = colour, normal, the moments S / X / Y of dL/dp', 15 = opacity
+            // term, 16..17 = the low-pass centre terms -- those are non-zero only when some pixel took the 2-D filter
+            // branch (rare for splats wider than a pixel), so their group is reduced and stored only then.  The record
             // buffer is not cleared: rec_flag[slot] (pre-cleared, one byte) says which parts are valid.
             {
                 const uint32_t slot = s_slot[j];
                 float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
-                float t[16] = {gp[0].x, gp[0].y, gp[1].x,  gp[1].y,  gp[2].x,  gp[2].y,  gp[3].x,  gp[3].y,
-                               gp[4].x, gp[4].y, gp[5].x, gp[5].y, gp[6].x, gp[6].y, gp[7].x, gp[8].y};
+                float t[16] = {gc0, gc1, gc2, gn0, gn1, gn2, gt0, gt1, gt2, gt3, gt4, gt5, gt6, gt7, gt8, gop};
                 const float y = wave_sum16_to_quads(t, lane_b3, lane_b2);
                 const bool slot_ok = slot < a.n_slots;  // false only in a frame that overflowed its presized capacity
                 if (quad_writer && slot_ok) rec[term_of_lane] = y;  // sixteen lanes, sixteen consecutive floats
                 const bool lp = __any(lowpass);
                 if (lp) {
-                    const float r4 = wave_sum4_to_rows(gp[7].y, gp[8].x, 0.0f, 0.0f);
+                    const float r4 = wave_sum4_to_rows(glp0, glp1, 0.0f, 0.0f);
                     if (row_writer && slot_ok) rec[16 + row] = r4;
                 }
                 if (lane == 0 && slot_ok) a.rec_flag[slot] = lp ? 3 : 1;
@@ -614,7 +646,7 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     float4 rq[BLEND_QUADS];
 #pragma unroll
                     for (int i = 0; i < BLEND_QUADS; i++) rq[i] = r[i];
-                    if (!a.no_fastpath && (__float_as_uint(rq[0].w) & REC_NO_LOWPASS)) qmask |= 16u;
+                    if (__float_as_uint(rq[0].w) & REC_AFFINE) qmask |= 16u;
 #pragma unroll
                     for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
                     s_slot[lane] = __float_as_uint(rq[0].z) + instance_number(__float_as_uint(rq[0].w), __float_as_uint(reinterpret_cast<const float*>(r)[31]),
@@ -632,9 +664,10 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                 const int j = (int)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 const bool nolp = (nolp_mask >> j) & 1ull;
+                const uint32_t general = (uint32_t)__builtin_amdgcn_readfirstlane(nolp ? 0 : 1);  // (see the one-wave kernel)
                 const uint32_t pos = (uint32_t)(hi - 1 - j);
                 const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-                float g[18];
+                float g[18];  // record order: 0..15 the common terms, 16..17 the low-pass centre terms
 #pragma unroll
                 for (int i = 0; i < 18; i++) {
                     g[i] = 0.0f;
@@ -658,7 +691,7 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     x.V_rec = fmaf(alpha, v_minus_rec, x.V_rec);
                     g[0] = fmaf(w, x.dpx0, g[0]); g[1] = fmaf(w, x.dpx1, g[1]); g[2] = fmaf(w, x.dpx2, g[2]);
                     g[3] = fmaf(w, x.dn0, g[3]); g[4] = fmaf(w, x.dn1, g[4]); g[5] = fmaf(w, x.dn2, g[5]);
-                    const float inv_cd = fast_rcp(c_d);
+                    const float inv_cd = e.inv_depth;
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
                     float dL_dz = 0.0f;
@@ -673,6 +706,15 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     dL_dalpha = fmaf(x.nTfbg, inv1ma, dL_dalpha);
                     const float dL_dG = q1.w * dL_dalpha;
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
+                    if (nolp) {
+                        const float mGi = (dL_dG * -G) * e.inv_pz;
+                        const float dpx_ = mGi * e.sx, dpy_ = mGi * e.sy;
+                        const float ndpz = fmaf(dpx_, e.sx, fmaf(dpy_, e.sy, (dL_dz * e.inv_pz) * e.inv_pz));
+                        acc_add(g[6], dpx_); acc_add(g[7], dpy_); acc_sub(g[8], ndpz);
+                        acc_fma(g[9], e.dx, dpx_); acc_fma(g[10], e.dx, dpy_); acc_fnma(g[11], e.dx, ndpz);
+                        acc_fma(g[12], e.dy, dpx_); acc_fma(g[13], e.dy, dpy_); acc_fnma(g[14], e.dy, ndpz);
+                    }
+                    if (general) {
                     if (e.in3d) {
                         const float mG = dL_dG * -G;
                         const float dL_dsx = fmaf(mG, e.sx, dL_dz * q3.z);
@@ -680,32 +722,35 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                         const float inv_pz = e.inv_pz;
                         const float dpx_ = dL_dsx * inv_pz, dpy_ = dL_dsy * inv_pz;
                         const float dpz_ = -fmaf(dpx_, e.sx, dpy_ * e.sy);
-                        const float dkx = fmaf(e.ly, dpz_, -(e.lz * dpy_)), dky = fmaf(e.lz, dpx_, -(e.lx * dpz_)),
-                                    dkz = fmaf(e.lx, dpy_, -(e.ly * dpx_));
-                        const float dlx = fmaf(dpy_, e.kz, -(dpz_ * e.ky)), dly = fmaf(dpz_, e.kx, -(dpx_ * e.kz)),
-                                    dlz = fmaf(dpx_, e.ky, -(dpy_ * e.kx));
+                        const float kx = fmaf(pxf, q3.z, -q2.x), ky = fmaf(pxf, q3.w, -q2.y), kz = fmaf(pxf, q4.x, -q2.z);
+                        const float lx = fmaf(pyf, q3.z, -q2.w), ly = fmaf(pyf, q3.w, -q3.x), lz = fmaf(pyf, q4.x, -q3.y);
+                        const float dkx = fmaf(ly, dpz_, -(lz * dpy_)), dky = fmaf(lz, dpx_, -(lx * dpz_)),
+                                    dkz = fmaf(lx, dpy_, -(ly * dpx_));
+                        const float dlx = fmaf(dpy_, kz, -(dpz_ * ky)), dly = fmaf(dpz_, kx, -(dpx_ * kz)),
+                                    dlz = fmaf(dpx_, ky, -(dpy_ * kx));
                         g[6] -= dkx; g[7] -= dky; g[8] -= dkz;
                         g[9] -= dlx; g[10] -= dly; g[11] -= dlz;
                         g[12] += fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * e.sx));
                         g[13] += fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * e.sy));
                         g[14] += fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz));
                     } else {
-                        const float c2 = dL_dG * (-G * FILTER_INV_SQUARE);
-                        g[15] = fmaf(c2, e.dx, g[15]);
-                        g[16] = fmaf(c2, e.dy, g[16]);
+                        const float c2 = dL_dG * (G * FILTER_INV_SQUARE);
+                        g[16] = fmaf(c2, e.dx, g[16]);
+                        g[17] = fmaf(c2, e.dy, g[17]);
                         g[14] += dL_dz;
                         lowpass = true;
                     }
-                    g[17] = fmaf(G, dL_dalpha, g[17]);
+                    }
+                    g[15] = fmaf(G, dL_dalpha, g[15]);
                 }
                 float t[16] = {g[0], g[1], g[2],  g[3],  g[4],  g[5],  g[6],  g[7],
-                               g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[17]};
+                               g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[15]};
                 float r[4];
                 wave_sum16_to_rows(t, r);
                 float* part = &s_part[wv][j][0];
                 if (row_writer) *reinterpret_cast<float4*>(part + 4 * row) = make_float4(r[0], r[1], r[2], r[3]);
                 if (__any(lowpass)) {
-                    const float r4 = wave_sum4_to_rows(g[15], g[16], 0.0f, 0.0f);
+                    const float r4 = wave_sum4_to_rows(g[16], g[17], 0.0f, 0.0f);
                     if (row_writer && row < 2) part[16 + row] = r4;
                     lp_mask |= 1ull << j;
                 }

@@ -26,6 +26,14 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
 }
 
+// acc += a * b / acc += a / acc -= a IN PLACE.  Written as asm so that the accumulator keeps its register: where two
+// arms of a wave-uniform branch update the same loop-carried accumulators, hipcc gives one arm fresh registers and
+// ends it with a chain of copies back (nine v_mov per visit in the blend backward's common arm).
+__device__ __forceinline__ void acc_fma(float& acc, float a, float b) { asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void acc_add(float& acc, float a) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(a)); }
+__device__ __forceinline__ void acc_sub(float& acc, float a) { asm volatile("v_sub_f32 %0, %0, %1" : "+v"(acc) : "v"(a)); }
+__device__ __forceinline__ void acc_fnma(float& acc, float a, float b) { asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(acc) : "v"(a), "v"(b)); }
+
 // Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (read it from lane 63).
 // quad_perm / row_ror inside each row of 16, then row_bcast:15 and row_bcast:31 (GFX9/CDNA).
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
@@ -273,106 +281,158 @@ constexpr float FAR_N = 100.0f;   // auxiliary.h:38
 constexpr float FILTER_INV_SQUARE = 2.0f;  // auxiliary.h:39
 
 // Ray/splat evaluation for one (pixel, splat) pair -- forward.cu:351-383 / backward.cu:267-301.
-// The fmaf placement is the contract shared with the oracle (oracle/surfel_oracle.c eval_pair).
+//
+// The reference forms k = x Tw - Tu, l = y Tw - Tv, p = k x l per (pixel, splat) pair (forward.cu:355-357: twelve
+// multiply-adds) and the interpolated depth s.x Tw.x + s.y Tw.y + Tw.z from s = p.xy / p.z.  p is AFFINE in the pixel,
+//     p(x, y) = x A + y B + D,     A = Tv x Tw,  B = Tw x Tu,  D = Tu x Tv,
+// and the depth is (p . Tw) / p.z = det(T) / p.z  (p . Tw = det[k; l; Tw] = det[Tu; Tv; Tw]).  For splats that qualify
+// (REC_AFFINE, below) the forward preprocess therefore stores the three vectors of
+//     p'(x, y) = (A (x - cx) + B (y - cy) + Dc) / det(T),     Dc = p(cx, cy),
+// expanded about the splat's own 3-sigma centre c (no cancellation between frame-sized terms: |x - cx| is a few
+// sigma wherever the splat matters) and evaluated in double from the single-precision T (splat_affine).  A pixel then
+// costs two subtractions and six FMAs instead of twelve, s = p'.xy / p'.z is unchanged (homogeneous), and
+//     depth = 1 / p'.z,   1 / depth = p'.z
+// come for free -- the reciprocal of the depth that the distortion terms need is no longer a second v_rcp_f32 -- and the
+// backward accumulates the moments of dL/dp' instead of dL/dTu, dL/dTv, dL/dTw (blend.hip, preprocess.hip: K8).
+//
+// REC_AFFINE (bit 31 of the record's tile-count word, q0.w) is a certificate, decided once per splat by the forward
+// preprocess: (a) the affine form is as accurate as the reference's own arithmetic to AFFINE_TOL in alpha -- a
+// first-order bound on the rounding of p' over the splat's alpha-cutoff box; it fails for splats seen nearly edge-on,
+// whose apparent aspect ratio exceeds ~15, and for a singular T -- (b) at every pixel where the low-pass exponent rho2d
+// could still pass the alpha test the 3-D exponent is the smaller one and is not in the tie band, so rho = rho3d and
+// the low-pass arithmetic is dead, (c) the interpolated depth stays above the near plane wherever alpha can pass.
+// Every other splat keeps T in its record and takes the general path: the reference's arithmetic, operation for
+// operation (the fmaf placement there is the contract shared with oracle/surfel_oracle.c eval_pair).
 struct PairEval {
-    float sx, sy, pz, inv_pz, kx, ky, kz, lx, ly, lz, rho3d, rho2d, depth, G, alpha, dx, dy;
-    bool in3d;  // the 3-D exponent was the smaller one (the low-pass fields rho2d, dx, dy are set only otherwise)
+    float sx, sy, inv_pz, rho3d, rho2d, depth, inv_depth, G, alpha, dx, dy;
+    bool in3d;  // the 3-D exponent was the smaller one (always, on the affine path)
 };
-constexpr uint32_t REC_NO_LOWPASS = 0x80000000u;  // bit 31 of the record's tile-count word (q0.w), see below
+constexpr uint32_t REC_AFFINE = 0x80000000u;
+constexpr float AFFINE_TOL = 4e-5f;  // bound on the relative error of alpha that the affine form may add (see splat_affine)
 
-// The ray-splat intersection of one pixel with one splat up to the two candidate exponents (forward.cu:349-372):
-//   rho3d = |s|^2 with s = p.xy / p.z, p = k x l;   rho2d = FilterInvSquare |centre - pixel|^2.
-// Returns false if p.z == 0.  s goes through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22
-// instructions); the only discrete decision that depends on it is `rho3d <= rho2d`: when the two are within 1e-5
-// relative of each other the exact quotient is recomputed, so the branch taken is the oracle's and the values
-// differ from it by ~1e-7 relative.  `tie` reports that case.
-__device__ __forceinline__ bool eval_rho(float pxf, float pyf, float cx, float cy, float Tux, float Tuy, float Tuz,
-                                         float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz, PairEval& e,
-                                         bool& tie) {
-    e.kx = fmaf(pxf, Twx, -Tux);
-    e.ky = fmaf(pxf, Twy, -Tuy);
-    e.kz = fmaf(pxf, Twz, -Tuz);
-    e.lx = fmaf(pyf, Twx, -Tvx);
-    e.ly = fmaf(pyf, Twy, -Tvy);
-    e.lz = fmaf(pyf, Twz, -Tvz);
-    const float ppx = fmaf(e.ky, e.lz, -(e.kz * e.ly));
-    const float ppy = fmaf(e.kz, e.lx, -(e.kx * e.lz));
-    const float ppz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
+// The nine coefficients of p' (record quads 2..4) and whether the splat qualifies by (a).
+struct SplatAffine {
+    float A[3], B[3], Dc[3];
+    bool ok;
+};
+// ex, ey: how far from the centre, in pixels, the splat is ever evaluated with a chance to pass the alpha test (its
+// alpha-cutoff box clipped to the frame); smax: |s| there (sqrt of the cutoff exponent).
+__device__ __forceinline__ void splat_affine(const float* T, float cx, float cy, float ex, float ey, float smax, SplatAffine& o) {
+    const double Tu[3] = {T[0], T[1], T[2]}, Tv[3] = {T[3], T[4], T[5]}, Tw[3] = {T[6], T[7], T[8]};
+    auto cross = [](const double* a, const double* b, double* c) {
+        c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double A[3], B[3], D[3], Dc[3];
+    cross(Tv, Tw, A);
+    cross(Tw, Tu, B);
+    cross(Tu, Tv, D);
+    const double det = Tu[0] * A[0] + Tu[1] * A[1] + Tu[2] * A[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Dc[i] = (double)cx * A[i] + (double)cy * B[i] + D[i];
+    const double g = 1.0 / det;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        o.A[i] = (float)(g * A[i]);
+        o.B[i] = (float)(g * B[i]);
+        o.Dc[i] = (float)(g * Dc[i]);
+    }
+    // First-order bound on what single precision does to p'_c = A'_c dx + B'_c dy + Dc'_c over |dx| <= ex, |dy| <= ey:
+    // the stored coefficients, dx / dy and the two FMAs each round once -> E_c <= 3 u (|A'_c| ex + |B'_c| ey + |Dc'_c|).
+    // s = p'.xy / p'.z, alpha ~ exp(-|s|^2 / 2):  |d alpha / alpha| <= smax (E_x + E_y + 2 smax E_z) / min |p'.z|.
+    const float u3 = 3.0f * 5.9604645e-8f;
+    const float Ex = fmaf(fabsf(o.A[0]), ex, fmaf(fabsf(o.B[0]), ey, fabsf(o.Dc[0])));
+    const float Ey = fmaf(fabsf(o.A[1]), ex, fmaf(fabsf(o.B[1]), ey, fabsf(o.Dc[1])));
+    const float vz = fmaf(fabsf(o.A[2]), ex, fabsf(o.B[2]) * ey);
+    const float Ez = vz + fabsf(o.Dc[2]);
+    const float pzmin = fabsf(o.Dc[2]) - vz;
+    const float bound = u3 * smax * (Ex + Ey + 2.0f * smax * Ez);
+    // (NaN / inf anywhere -- det == 0, overflow of p / det -- fails the comparisons)
+    o.ok = pzmin > 0.5f * fabsf(o.Dc[2]) && bound <= AFFINE_TOL * pzmin && fabsf(o.Dc[2]) < 1e30f && Ex < 1e30f && Ey < 1e30f;
+}
+
+// The ray-splat intersection of one pixel with an AFFINE splat up to the two candidate exponents (forward.cu:349-372):
+//   rho3d = |s|^2 with s = p.xy / p.z;   rho2d = FilterInvSquare |centre - pixel|^2.
+// Returns false if p.z == 0.  Same arithmetic as eval_pair's affine path: parts (b) of the REC_AFFINE certificate are
+// evaluated with it.  `tie` = the two exponents are within 1e-5 relative of each other (then (b) fails).
+__device__ __forceinline__ bool eval_rho_affine(float pxf, float pyf, float cx, float cy, const SplatAffine& f, PairEval& e,
+                                                bool& tie) {
+    e.dx = pxf - cx;
+    e.dy = pyf - cy;
+    const float ppx = fmaf(f.A[0], e.dx, fmaf(f.B[0], e.dy, f.Dc[0]));
+    const float ppy = fmaf(f.A[1], e.dx, fmaf(f.B[1], e.dy, f.Dc[1]));
+    const float ppz = fmaf(f.A[2], e.dx, fmaf(f.B[2], e.dy, f.Dc[2]));
     tie = false;
     if (ppz == 0.0f) return false;
-    e.pz = ppz;
-    e.dx = cx - pxf;
-    e.dy = cy - pyf;
     e.rho2d = FILTER_INV_SQUARE * fmaf(e.dx, e.dx, e.dy * e.dy);
     const float inv = __builtin_amdgcn_rcpf(ppz);
-    e.inv_pz = inv;
     e.sx = ppx * inv;
     e.sy = ppy * inv;
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
-    if (fabsf(e.rho3d - e.rho2d) <= 1e-5f * e.rho2d) {
-        tie = true;
-        e.sx = ppx / ppz;
-        e.sy = ppy / ppz;
-        e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
-    }
+    tie = fabsf(e.rho3d - e.rho2d) <= 1e-5f * e.rho2d;
     return true;
 }
 
-// One pixel against one splat: forward.cu:349-393 up to alpha.  `nolp` (wave-uniform) = the splat's record carries
-// REC_NO_LOWPASS: preprocess has checked, with this very arithmetic (eval_rho), that at every pixel where the
-// low-pass exponent rho2d could still pass the alpha test the 3-D exponent is the smaller one and is not in the tie
-// band -- so rho = rho3d, and the low-pass arithmetic (rho2d, the tie test, two selects: 11 instructions of the ~46)
-// is skipped with bit-identical results.  (Where rho2d is too large to pass, min(rho3d, rho2d) fails the alpha test
-// whichever of the two is used.)  The flag also certifies that the interpolated depth stays above the near plane
-// wherever alpha can pass (depth is affine in s and |s|^2 <= t there), which makes that test redundant too.  The general extras sit inside one uniform branch that only refines values the
-// common code has already produced, so the two kinds of splat share everything else without register shuffling.
-__device__ __forceinline__ bool eval_pair(bool nolp, float pxf, float pyf, float cx, float cy, float Tux, float Tuy,
-                                          float Tuz, float Tvx, float Tvy, float Tvz, float Twx, float Twy, float Twz,
+// One pixel against one splat: forward.cu:349-393 up to alpha.  `affine` (wave-uniform) = the splat's record carries
+// REC_AFFINE; c0..c8 are then A', B', Dc', otherwise Tu, Tv, Tw (record quads 2..4).  The two kinds of splat share
+// everything after p: the general extras sit inside one uniform branch that only refines values the common code has
+// already produced.
+__device__ __forceinline__ bool eval_pair(bool affine, float pxf, float pyf, float cx, float cy, float c0, float c1,
+                                          float c2, float c3, float c4, float c5, float c6, float c7, float c8,
                                           float opa, PairEval& e) {
     // No early exits: the three rejections (p.z == 0, depth < near, alpha < 1/255) are ANDed into the returned
     // predicate at the end.  Every lane runs every instruction anyway (a VALU instruction costs the same whatever EXEC
     // says); an early `return false` only buys an EXEC region -- s_and_saveexec, a branch, the restore -- around the
-    // rest, and those scalar instructions are what the blend kernels' waves are short of (-2 % blend_bwd, -x % blend_fwd,
-    // profiles/r04_ab_blend_bwd.txt).  A lane with p.z == 0 computes with inf / NaN and is rejected by `ok`; lanes that
-    // pass see exactly the arithmetic they saw before.
-    e.kx = fmaf(pxf, Twx, -Tux);
-    e.ky = fmaf(pxf, Twy, -Tuy);
-    e.kz = fmaf(pxf, Twz, -Tuz);
-    e.lx = fmaf(pyf, Twx, -Tvx);
-    e.ly = fmaf(pyf, Twy, -Tvy);
-    e.lz = fmaf(pyf, Twz, -Tvz);
-    const float ppx = fmaf(e.ky, e.lz, -(e.kz * e.ly));
-    const float ppy = fmaf(e.kz, e.lx, -(e.kx * e.lz));
-    const float ppz = fmaf(e.kx, e.ly, -(e.ky * e.lx));
-    bool ok = ppz != 0.0f;  // forward.cu:354 `if (p.z == 0.0) continue;`
-    e.pz = ppz;
-    // s = p.xy / p.z through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22 instructions), see eval_rho
-    const float inv = __builtin_amdgcn_rcpf(ppz);
-    e.inv_pz = inv;
+    // rest, and those scalar instructions are what the blend kernels' waves are short of (-3 % blend_bwd, -6 % blend_fwd,
+    // profiles/r04_ab_blend_bwd.txt).  A lane with p.z == 0 computes with inf / NaN and is rejected by `ok`.
+    // The affine form is the main line; a splat without REC_AFFINE redoes the evaluation the reference's way inside ONE
+    // uniform region, so that the common case passes a single (taken) branch here.  Written as an if / else the two forms
+    // cost every visit four branches (hipcc lowers the wave-uniform bool to a lane mask and a diamond to two
+    // conditional branches): blend_bwd 0.79 -> 0.92 ms, all of what the affine form had gained.
+    e.dx = pxf - cx;
+    e.dy = pyf - cy;
+    float ppx = fmaf(c0, e.dx, fmaf(c3, e.dy, c6));
+    float ppy = fmaf(c1, e.dx, fmaf(c4, e.dy, c7));
+    float ppz = fmaf(c2, e.dx, fmaf(c5, e.dy, c8));
+    // s = p.xy / p.z through one v_rcp_f32 (1 ulp) instead of two IEEE divisions (~22 instructions); the only discrete
+    // decision that depends on it is `rho3d <= rho2d` on the general path: when the two are within 1e-5 relative of each
+    // other the exact quotient is recomputed, so the branch taken is the oracle's.
+    float inv = __builtin_amdgcn_rcpf(ppz);
     e.sx = ppx * inv;
     e.sy = ppy * inv;
     e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
     e.in3d = true;
     float rho = e.rho3d;
-    e.depth = fmaf(e.sx, Twx, e.sy * Twy) + Twz;
-    if (!nolp) {
-        e.dx = cx - pxf;
-        e.dy = cy - pyf;
+    e.depth = inv;      // affine: det(T) / p.z with p pre-divided by det(T)
+    e.inv_depth = ppz;
+    bool ok = ppz != 0.0f;  // forward.cu:354 `if (p.z == 0.0) continue;`
+    if (!affine) {  // forward.cu:355-378 with (c0..c2) = Tu, (c3..c5) = Tv, (c6..c8) = Tw
+        const float kx = fmaf(pxf, c6, -c0), ky = fmaf(pxf, c7, -c1), kz = fmaf(pxf, c8, -c2);
+        const float lx = fmaf(pyf, c6, -c3), ly = fmaf(pyf, c7, -c4), lz = fmaf(pyf, c8, -c5);
+        ppx = fmaf(ky, lz, -(kz * ly));
+        ppy = fmaf(kz, lx, -(kx * lz));
+        ppz = fmaf(kx, ly, -(ky * lx));
+        inv = __builtin_amdgcn_rcpf(ppz);
+        e.sx = ppx * inv;
+        e.sy = ppy * inv;
+        e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
         e.rho2d = FILTER_INV_SQUARE * fmaf(e.dx, e.dx, e.dy * e.dy);
+        float d3 = fmaf(e.sx, c6, e.sy * c7) + c8;  // forward.cu:373
         if (fabsf(e.rho3d - e.rho2d) <= 1e-5f * e.rho2d) {  // too close to call: exact quotient
             e.sx = ppx / ppz;
             e.sy = ppy / ppz;
             e.rho3d = fmaf(e.sx, e.sx, e.sy * e.sy);
-            e.depth = fmaf(e.sx, Twx, e.sy * Twy) + Twz;
+            d3 = fmaf(e.sx, c6, e.sy * c7) + c8;
         }
         // rho = min(rho3d, rho2d) and the depth select share one compare.  (NaN rho3d -- 0 * inf when p.z is
         // denormal -- takes the rho2d side in both, like fminf.)
         e.in3d = e.rho3d <= e.rho2d;
         rho = e.in3d ? e.rho3d : e.rho2d;
-        e.depth = e.in3d ? e.depth : Twz;
-        // (REC_NO_LOWPASS also certifies depth >= near wherever the splat can pass the alpha test)
-        ok = ok && !(e.depth < NEAR_N);  // forward.cu:378 `if (depth < near_n) continue;`
+        e.depth = e.in3d ? d3 : c8;
+        e.inv_depth = __builtin_amdgcn_rcpf(e.depth);
+        // forward.cu:378 `if (depth < near_n) continue;` (REC_AFFINE certifies depth >= near wherever the splat can pass)
+        ok = ppz != 0.0f && !(e.depth < NEAR_N);
     }
+    e.inv_pz = inv;
     // forward.cu:383-385 `power = -0.5 rho; if (power > 0) continue;` can never fire (rho is a sum of squares),
     // and exp(power) = exp2(rho * (-0.5 log2 e)): scaling by -0.5 is exact, so folding it into the constant
     // rounds exactly like (-0.5f * rho) * log2e.  One v_exp_f32: rho in [0, 11.2] for anything that can pass,

@@ -11,20 +11,43 @@ namespace g4s {
 constexpr int TILE = 16;           // tile edge in pixels (part of the output definition, auxiliary.h:66-76)
 constexpr int REC_FLOATS = 32;     // per-Gaussian splat record, 128 B = 8 x float4 (layout below)
 constexpr int REC_QUADS = REC_FLOATS / 4;
-constexpr int BLEND_QUADS = 5;     // q0..q4: what the per-pixel arithmetic needs (q5..q7 only steer culling)
-constexpr int GRAD_FLOATS = 18;    // gradient terms per instance (3 colour, 3 normal, 9 T, 2 mean2D, 1 opacity)
-constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 16-byte aligned; last two unused)
+constexpr int BLEND_QUADS = 5;     // quads per staged entry in LDS: what the per-pixel arithmetic needs (layout below)
+// Gradient terms per (tile, Gaussian) instance, in record order: [0..2] colour, [3..5] normal, [6..14] the T terms,
+// [15] opacity, [16..17] the low-pass centre terms (mean2D).  The T terms of a REC_AFFINE splat are the moments of the adjoint of p' (the affine
+// ray-splat intersection of g4s_device.h): [6..8] S = sum dL/dp', [9..11] X = sum (x - cx) dL/dp', [12..14] Y = sum
+// (y - cy) dL/dp' -- the cross products of backward.cu:396-426 are linear in the pixel and are taken once per Gaussian
+// by K8; those of any other splat are dL/dTu, dL/dTv, dL/dTw themselves.
+constexpr int GRAD_FLOATS = 18;
+constexpr int GRAD_STRIDE = 20;    // floats per stored gradient record (80 B, 16-byte aligned; the last two unused)
 // Splat record (written by the forward preprocess, read by emit / blend / backward):
-//   q0 = (centre.x, centre.y, bits(inst_off), bits(binned rect width | height << 16 | REC_NO_LOWPASS))
+//   q0 = (centre.x, centre.y, bits(inst_off), bits(binned rect width | height << 16 | REC_AFFINE))
 //   q1 = (normal.xyz (view space, flipped towards the camera), opacity)
-//   q2 = (Tu.x, Tu.y, Tu.z, Tv.x)   q3 = (Tv.y, Tv.z, Tw.x, Tw.y)   q4 = (Tw.z, r, g, b)
-//   q5 = conservative pixel bounding box (x0, y0, x1, y1) of the region where this splat can pass
-//        the 1/255 alpha test (empty: x0 > x1)
+//   q2 = (Tu.x, Tu.y, Tu.z, Tv.x)   q3 = (Tv.y, Tv.z, Tw.x, Tw.y)   q4 = (Tw.z, r, g, b) -- or, for REC_AFFINE splats,
+//   q2 = (A'.x, A'.y, A'.z, B'.x)   q3 = (B'.y, B'.z, Dc'.x, Dc'.y)   q4 = (Dc'.z, r, g, b): the affine ray-splat
+//        intersection p'(x, y) = A' (x - cx) + B' (y - cy) + Dc' (g4s_device.h: splat_affine)
+//   q5 = (bits(bx0), bits(bx1), Tw.z, bits(by0 | by1 << 16)): the bounding box, in 8x8-pixel quadrants and clamped to the
+//        frame, of the region where this splat can pass the 1/255 alpha test (box_quadrants below; empty: bx0 > bx1; a
+//        frame is at most 131 070 quadrants across and 65 534 down); T[8] (the densification surrogate of K8 needs it
+//        whatever quads 2..4 hold)
 //   q6 = (ex, ey, ux, uy), q7 = (1/a^2, 1/b^2, r2, bits(binned rect x0 | y0 << 16)): the same region exactly -- the
 //        union of the ellipse (centre e, unit major axis u, semi-axes a >= b) that the alpha-cutoff disk of the splat
 //        projects to and of the low-pass disk |pixel - centre|^2 <= r2 -- slightly enlarged; 1/a^2 = 0: no ellipse, use
 //        the box.  The binned rect lives in q0.w / q7.w: q7 shares its 64-byte line with q4, which the blend backward
 //        reads anyway, so an entry's instance number (gradient-record slot - inst_off) costs it no extra memory traffic.
+// The blend loops keep q0..q4 of every staged entry in LDS (BLEND_QUADS); q5..q7 only steer culling.
+// The 8x8-pixel quadrants [lo, hi] (indices, clamped to the frame) that hold a pixel of the float interval [lo, hi];
+// empty: lo = 1 > hi = 0.  Quadrants are all the blend forward asks the box about, and since they start at multiples of
+// eight nothing is lost against pixel bounds: x0 > 8 k + 7 <=> floor(ceil(x0) / 8) > k, x1 < 8 k <=> floor(floor(x1) / 8) < k.
+__host__ __device__ inline void box_quadrants(float lo, float hi, int extent, uint32_t& q0, uint32_t& q1) {
+    // pixel centres sit on integer coordinates: the pixels inside [lo, hi] are ceil(lo) .. floor(hi)
+    const float l = ceilf(lo), h = floorf(hi);
+    const float top = (float)(extent - 1);
+    q0 = 1u;
+    q1 = 0u;
+    if (!(l <= h) || !(h >= 0.0f) || !(l <= top)) return;  // empty (also NaN)
+    q0 = (l > 0.0f ? (uint32_t)l : 0u) >> 3;
+    q1 = (h < top ? (uint32_t)h : (uint32_t)(extent - 1)) >> 3;
+}
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 // Keys per thread of the radix passes (a workgroup of 256 threads owns 256 * ITEMS consecutive keys).
 #ifndef G4S_SORT_ITEMS_U32
@@ -45,7 +68,7 @@ constexpr int ENTRY_TILE_SHIFT = 32;
 __host__ __device__ inline uint32_t entry_idx(uint64_t e) { return (uint32_t)e; }
 __host__ __device__ inline uint32_t entry_tile(uint64_t e) { return (uint32_t)(e >> ENTRY_TILE_SHIFT); }
 // The rect of tiles a Gaussian is binned into, as the record keeps it: extent word = width | height << 16 (bit 31 is
-// REC_NO_LOWPASS: at most 65 535 tiles across, 32 767 down), origin word = x0 | y0 << 16; row-major instance numbering.
+// REC_AFFINE: at most 65 535 tiles across, 32 767 down), origin word = x0 | y0 << 16; row-major instance numbering.
 __host__ __device__ inline uint32_t rect_extent_word(int w, int h) { return (uint32_t)w | ((uint32_t)h << 16); }
 __host__ __device__ inline uint32_t rect_tiles(uint32_t extent_word) {
     return (extent_word & 0xFFFFu) * ((extent_word >> 16) & 0x7FFFu);
@@ -141,6 +164,7 @@ struct PreprocessArgs {
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;
     bool sh_vec16;  // shs is [P,16,3] on a 16-byte aligned base
+    bool no_fastpath;  // tests (option "no_fastpath"): no splat is given REC_AFFINE -- every one takes the reference's arithmetic
     const float* shs_rest;  // split layout (g4s_rasterizer_forward_split_sh): shs = [P,1,3], shs_rest = [P,M-1,3]; NULL = packed
     float* rec;
     uint8_t* clamped;
@@ -198,7 +222,6 @@ struct BlendFwdArgs {
     uint8_t* qhit;  // per sorted instance: bit q set if some pixel of quadrant q blended it (pre-zeroed)
     uint32_t* tile_depth;  // per tile (0, number of (entry, quadrant) pairs blended): the backward's work, for its ordering
     int box_only;   // tests (option "box_only"): skip quadrants by the bounding box only
-    int no_fastpath;  // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
     float* out_color;
     float* out_others;
 };
@@ -223,7 +246,6 @@ struct BlendBwdArgs {
     // scan over ALL binned instances) can lie beyond it: such a record is dropped, never written (the frame is
     // flagged invalid in the status word; memory stays safe).
     uint32_t n_slots;
-    int no_fastpath;   // tests (option "no_fastpath"): ignore REC_NO_LOWPASS
     // deep tiles (more than hot_threshold live list positions) are left to blend_bwd_hot_kernel: the one-wave
     // kernel appends them to hot_list (hot_count pre-cleared), the four-wave kernel runs behind it
     int hot_threshold;  // < 0: all tiles go to the four-wave kernel (frames with too few tiles to fill the GPU one wave each)
@@ -242,6 +264,8 @@ void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 
 struct PreprocessBwdArgs {
     int P, D, M, W, H;  // W,H: the truncated values of backward.cu:618-619
+    int frame_W, frame_H;    // the frame's real size and the forward's scale_modifier: K8 re-forms the forward's T, which
+    float scale_modifier;    // the moments written by the blend backward refer to (the reference's backward ignores both)
     const float *means3D, *scales, *rotations, *shs, *transMat_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *campos;
     const int* radii;

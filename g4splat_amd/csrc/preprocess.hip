@@ -193,12 +193,12 @@ __device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, 
     // (no validity flag: 1 / a^2 = out[4] > 0 says there is an ellipse; out[7] belongs to the caller)
 }
 
-// REC_NO_LOWPASS: true if (a) the interpolated depth cannot fall below the near plane where the splat passes the alpha
-// test and (b) the low-pass exponent rho2d can never be the smaller one where it matters -- at every
-// integer pixel whose rho2d could still pass the alpha test (a disk of <= 2.4 px around the centre, <= 25 pixels)
-// the 3-D exponent is smaller and outside the tie band -- evaluated with the blend loops' own arithmetic
-// (eval_rho), so that eval_pair(nolp = true) is bit-identical to eval_pair(nolp = false) for this splat (g4s_device.h).
-__device__ __forceinline__ bool lowpass_never_matters(const float* T, float cx, float cy, float opa) {
+// Parts (b) and (c) of the REC_AFFINE certificate (g4s_device.h): true if the interpolated depth cannot fall below the
+// near plane where the splat passes the alpha test and the low-pass exponent rho2d can never be the smaller one where
+// it matters -- at every integer pixel whose rho2d could still pass the alpha test (a disk of <= 2.4 px around the
+// centre, <= 25 pixels) the 3-D exponent is smaller and outside the tie band -- evaluated with the blend loops' own
+// affine arithmetic (eval_rho_affine).
+__device__ __forceinline__ bool lowpass_never_matters(const float* T, const SplatAffine& af, float cx, float cy, float opa) {
     const float thr = 2.0f * logf(255.0f * opa);
     if (!(thr > 0.0f) || !(fabsf(cx) < 1e7f) || !(fabsf(cy) < 1e7f)) return false;
     const float tt = thr * 1.01f + 0.1f;
@@ -207,11 +207,11 @@ __device__ __forceinline__ bool lowpass_never_matters(const float* T, float cx, 
     const float r = sqrtf(0.5f * tt) + 0.01f;
     for (int yy = (int)ceilf(cy - r); yy <= (int)floorf(cy + r); yy++)
         for (int xx = (int)ceilf(cx - r); xx <= (int)floorf(cx + r); xx++) {
-            const float ddx = cx - (float)xx, ddy = cy - (float)yy;
-            if (FILTER_INV_SQUARE * fmaf(ddx, ddx, ddy * ddy) > tt) continue;  // eval_rho's rho2d, before the costly part
+            const float ddx = (float)xx - cx, ddy = (float)yy - cy;
+            if (FILTER_INV_SQUARE * fmaf(ddx, ddx, ddy * ddy) > tt) continue;  // eval_rho_affine's rho2d, before the costly part
             PairEval e;
             bool tie;
-            if (!eval_rho((float)xx, (float)yy, cx, cy, T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], T[8], e, tie)) continue;
+            if (!eval_rho_affine((float)xx, (float)yy, cx, cy, af, e, tie)) continue;
             if (e.rho2d > tt) continue;
             if (tie || !(e.rho3d <= e.rho2d)) return false;
         }
@@ -323,8 +323,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     float rec[REC_FLOATS];
 #pragma unroll
     for (int i = 0; i < REC_FLOATS; i++) rec[i] = 0.0f;
-    rec[20] = 1.0f;  // empty box: x0 > x1
-    rec[21] = 1.0f;
+    rec[20] = __uint_as_float(1u);  // empty box: x0 = 1 > x1 = 0
 
     if (in_range) {
         const F3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
@@ -344,7 +343,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                 for (int i = 0; i < 9; i++) T[i] = a.transMat_precomp[9 * (size_t)idx + i];
                 normal = mk3(0.0f, 0.0f, 1.0f);
             }
-            // T is kept even if the Gaussian is culled below (forward.cu:197-200)
+            // T is kept even if the Gaussian is culled below (forward.cu:197-200); REC_AFFINE splats replace it by p'
 #pragma unroll
             for (int i = 0; i < 9; i++) rec[8 + i] = T[i];
             const float cosv = -((p_view.x * normal.x + p_view.y * normal.y) + p_view.z * normal.z);
@@ -381,9 +380,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         if (touched != 0) a.tight_rect[idx] = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)(tx1 - tx0));
                         rec[0] = cx;
                         rec[1] = cy;
-                        // q0.w = binned rect (width | height << 16) | REC_NO_LOWPASS; q7.w = its origin (x0 | y0 << 16)
-                        rec[3] = __uint_as_float(rect_extent_word(tx1 - tx0, ty1 - ty0) |
-                                                 (lowpass_never_matters(T, cx, cy, opa) ? REC_NO_LOWPASS : 0u));
+                        // q0.w = binned rect (width | height << 16) | REC_AFFINE; q7.w = its origin (x0 | y0 << 16)
+                        // Does the splat qualify for the affine ray-splat intersection (REC_AFFINE, g4s_device.h)?  Then
+                        // quads 2..4 carry A', B', Dc' instead of T.  Only splats that are binned can be asked for it.
+                        bool affine = false;
+                        if (touched != 0 && !a.no_fastpath) {
+                            // how far from the centre the splat is evaluated with a chance to pass: its alpha-cutoff box, in the frame
+                            const float bx0 = fmaxf(box.x, 0.0f), bx1 = fminf(box.z, (float)(a.W - 1));
+                            const float by0 = fmaxf(box.y, 0.0f), by1 = fminf(box.w, (float)(a.H - 1));
+                            const float ex = fmaxf(fabsf(bx0 - cx), fabsf(bx1 - cx)), ey = fmaxf(fabsf(by0 - cy), fabsf(by1 - cy));
+                            const float smax = sqrtf(2.0f * logf(255.0f * opa) * 1.001f + 1e-3f);
+                            SplatAffine af;
+                            splat_affine(T, cx, cy, ex, ey, smax, af);
+                            affine = af.ok && lowpass_never_matters(T, af, cx, cy, opa);
+                            if (affine) {
+#pragma unroll
+                                for (int i = 0; i < 3; i++) {
+                                    rec[8 + i] = af.A[i];
+                                    rec[11 + i] = af.B[i];
+                                    rec[14 + i] = af.Dc[i];
+                                }
+                            }
+                        }
+                        rec[3] = __uint_as_float(rect_extent_word(tx1 - tx0, ty1 - ty0) | (affine ? REC_AFFINE : 0u));
                         rec[4] = normal.x;
                         rec[5] = normal.y;
                         rec[6] = normal.z;
@@ -391,10 +410,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
                         rec[17] = rgb[0];
                         rec[18] = rgb[1];
                         rec[19] = rgb[2];
-                        rec[20] = box.x;
-                        rec[21] = box.y;
-                        rec[22] = box.z;
-                        rec[23] = box.w;
+                        uint32_t bx0, bx1, by0, by1;
+                        box_quadrants(box.x, box.z, a.W, bx0, bx1);
+                        box_quadrants(box.y, box.w, a.H, by0, by1);
+                        rec[20] = __uint_as_float(bx0);
+                        rec[21] = __uint_as_float(bx1);
+                        rec[22] = T[8];
+                        rec[23] = __uint_as_float(by0 | (by1 << 16));
                         if (touched != 0) alpha_cutoff_ellipse(T, opa, rec + 24);  // rec[28] (1 / a^2) stays 0 when there is no ellipse
                         rec[31] = __uint_as_float((uint32_t)tx0 | ((uint32_t)ty0 << 16));
                     }
@@ -858,18 +880,19 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 
     if (visible) {
         const bool precomp = (a.scales == nullptr);
-        const float4 q4 = rq[4];
-        const float depth_T8 = q4.x;  // transMats[idx*9+8]
-        float T[9];
+        const float4 q0 = rq[0], q2 = rq[2], q3 = rq[3], q4 = rq[4], q5 = rq[5];
+        const bool affine = (__float_as_uint(q0.w) & REC_AFFINE) != 0;
+        const float depth_T8 = q5.z;  // transMats[idx*9+8]
+        float T[9];   // the backward's own T (scale_modifier ignored, truncated W / H: backward.cu:481, 618-619)
+        float Tf[9];  // the forward's T: what the moments of a REC_AFFINE splat refer to
         float Pm[3][4];
         float R[9];
         F3 normal = mk3(0, 0, 0), p_orig = mk3(0, 0, 0);
         float sx = 0, sy = 0;
         float4 rot = make_float4(1, 0, 0, 0);
         if (precomp) {
-            const float4 q2 = rq[2], q3 = rq[3];
-            T[0] = q2.x; T[1] = q2.y; T[2] = q2.z; T[3] = q2.w; T[4] = q3.x; T[5] = q3.y; T[6] = q3.z; T[7] = q3.w;
-            T[8] = q4.x;
+#pragma unroll
+            for (int i = 0; i < 9; i++) Tf[i] = T[i] = a.transMat_precomp[9 * (size_t)idx + i];
         } else {
             p_orig = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
             rot = reinterpret_cast<const float4*>(a.rotations)[idx];
@@ -896,10 +919,50 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                     T[c * 3 + r] = Mrow[r][0] * Pm[c][0] + Mrow[r][1] * Pm[c][1] + Mrow[r][2] * Pm[c][2] +
                                    Mrow[r][3] * Pm[c][3];
             normal = xform_vec_4x3(mk3(R[6], R[7], R[8]), a.viewmatrix);
+            if (affine) compute_transmat(p_orig, sx, sy, a.scale_modifier, R, a.projmatrix, a.frame_W, a.frame_H, Tf);  // as K1 did
         }
         float dL_dT[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) dL_dT[i] = g[6 + i];
+        for (int i = 0; i < 9; i++) dL_dT[i] = g[6 + i];  // general path: the blend backward summed dL/dTu, dL/dTv, dL/dTw
+        // REC_AFFINE: dL/dT from the moments S, X, Y of dL/dp' (backward.cu:396-426, taken once per Gaussian instead of
+        // once per pixel).  With Q(x, y) = x A + y B + D = k x l, A = Tv x Tw, B = Tw x Tu, D = Tu x Tv, det = det(T) and
+        // p' = gam Q, gam = 1 / det:
+        //   dL = sum_pixels dL/dp' . (gam dQ + Q dgam),   sum dL/dp' . p' = -sum depth dL/ddepth =: -Zd   (s is homogeneous in p')
+        //   dL/dTu = gam (Y x Tw + S x lc) + gdet A         kc = cx Tw - Tu, lc = cy Tw - Tv (k, l at the splat centre:
+        //   dL/dTv = gam (Tw x X + kc x S) + gdet B          the moments X, Y are taken about it, so the frame-sized
+        //   dL/dTw = -cx (.)u - cy (.)v + gam (lc x X + Y x kc) + gdet D      terms cancel here, once, not in the sums)
+        // with gdet = Zd / det = dL/d det (depth = det / Q.z), (.)u / (.)v the gam parts of the first two lines.
+        if (affine) {
+            const float cx = q0.x, cy = q0.y;
+            const F3 Ap = mk3(q2.x, q2.y, q2.z), Bp = mk3(q2.w, q3.x, q3.y), Dp = mk3(q3.z, q3.w, q4.x);
+            const F3 S = mk3(g[6], g[7], g[8]), X = mk3(g[9], g[10], g[11]), Y = mk3(g[12], g[13], g[14]);
+            const F3 Tu = mk3(Tf[0], Tf[1], Tf[2]), Tv = mk3(Tf[3], Tf[4], Tf[5]), Tw = mk3(Tf[6], Tf[7], Tf[8]);
+            auto crs = [](F3 u, F3 v) { return mk3(fmaf(u.y, v.z, -(u.z * v.y)), fmaf(u.z, v.x, -(u.x * v.z)), fmaf(u.x, v.y, -(u.y * v.x))); };
+            auto dot3 = [](F3 u, F3 v) { return fmaf(u.x, v.x, fmaf(u.y, v.y, u.z * v.z)); };
+            const float Zd = -(dot3(Ap, X) + dot3(Bp, Y) + dot3(Dp, S));
+            const F3 kc = mk3(fmaf(cx, Tw.x, -Tu.x), fmaf(cx, Tw.y, -Tu.y), fmaf(cx, Tw.z, -Tu.z));
+            const F3 lc = mk3(fmaf(cy, Tw.x, -Tv.x), fmaf(cy, Tw.y, -Tv.y), fmaf(cy, Tw.z, -Tv.z));
+            // det(T) = (kc x lc) . Tw in double: near edge-on splats lose digits in the 2 x 2 minors
+            const double kd[3] = {(double)cx * Tw.x - Tu.x, (double)cx * Tw.y - Tu.y, (double)cx * Tw.z - Tu.z};
+            const double ld[3] = {(double)cy * Tw.x - Tv.x, (double)cy * Tw.y - Tv.y, (double)cy * Tw.z - Tv.z};
+            const double det = (kd[1] * ld[2] - kd[2] * ld[1]) * Tw.x + (kd[2] * ld[0] - kd[0] * ld[2]) * Tw.y +
+                               (kd[0] * ld[1] - kd[1] * ld[0]) * Tw.z;
+            const double inv_det = 1.0 / det;  // (REC_AFFINE: det(T) is invertible)
+            const float gam = (float)inv_det;
+            const float gdet = (float)((double)Zd * inv_det);
+            const F3 u1 = crs(Y, Tw), u2 = crs(S, lc), v1 = crs(Tw, X), v2 = crs(kc, S), w1 = crs(lc, X), w2 = crs(Y, kc);
+            const F3 U = mk3(gam * (u1.x + u2.x), gam * (u1.y + u2.y), gam * (u1.z + u2.z));
+            const F3 V = mk3(gam * (v1.x + v2.x), gam * (v1.y + v2.y), gam * (v1.z + v2.z));
+            const F3 Wg = mk3(gam * (w1.x + w2.x), gam * (w1.y + w2.y), gam * (w1.z + w2.z));
+            const F3 Aa = crs(Tv, Tw), Ba = crs(Tw, Tu), Da = crs(Tu, Tv);
+            dL_dT[0] = fmaf(gdet, Aa.x, U.x); dL_dT[1] = fmaf(gdet, Aa.y, U.y); dL_dT[2] = fmaf(gdet, Aa.z, U.z);
+            dL_dT[3] = fmaf(gdet, Ba.x, V.x); dL_dT[4] = fmaf(gdet, Ba.y, V.y); dL_dT[5] = fmaf(gdet, Ba.z, V.z);
+            dL_dT[6] = fmaf(gdet, Da.x, Wg.x - fmaf(cx, U.x, cy * V.x));
+            dL_dT[7] = fmaf(gdet, Da.y, Wg.y - fmaf(cx, U.y, cy * V.y));
+            dL_dT[8] = fmaf(gdet, Da.z, Wg.z - fmaf(cx, U.z, cy * V.z));
+#pragma unroll
+            for (int i = 0; i < 9; i++) dT_out[i] = dL_dT[i];
+        }
         const float mx = g[15], my = g[16];
         bool early_out = false;
         if (mx != 0 || my != 0) {  // backward.cu:513-556, low-pass centre path (cutoff-1 formula)

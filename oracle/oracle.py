@@ -184,6 +184,47 @@ def pixel_margins(o):
     return out
 
 
+def skip_suspects(o, margin):
+    """(int64[n] flat pixel indices, int32[n] Gaussian ids): the (pixel, Gaussian) pairs of Oracle `o`'s forward whose skip
+    decision (alpha vs 1/255, depth vs near) sits within `margin` of its threshold and is reached before the pixel stops.
+    See oracle_skip_suspects in surfel_oracle.c."""
+    fw = o._fw
+    if fw["P"] == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int32)
+    tm = fw["a"]["transMat"]
+    tmp = _ptr(tm if tm is not None and tm.size else None)
+    L = lib()
+    L.oracle_skip_suspects.restype = ctypes.c_long
+    cap = 1 << 16
+    while True:
+        pix, gid = np.zeros(cap, np.int64), np.zeros(cap, np.int32)
+        n = int(L.oracle_skip_suspects(o._s, tmp, ctypes.c_float(margin), ctypes.c_long(cap),
+                                       ctypes.c_void_p(pix.ctypes.data), ctypes.c_void_p(gid.ctypes.data)))
+        if n <= cap:
+            return pix[:n], gid[:n]
+        cap = n
+
+
+def pixel_alternatives(o, pix_ids, margin):
+    """float64[len(pix_ids), ALT, 12]: the outputs of the listed pixels (flat indices y * W + x) with their decisions
+    that sit within `margin` of a threshold taken the other way, one combination per ALT slot (slot 0 = as rendered).
+    Columns: colour 0..2, the seven `others` maps 3..9, Gaussian id of the last / median contributor 10, 11 (-1 = none;
+    exact in float32 below 2^24 Gaussians).  See oracle_pixel_alternatives in surfel_oracle.c."""
+    fw = o._fw
+    ids = np.ascontiguousarray(np.asarray(pix_ids, dtype=np.int64))
+    L = lib()
+    L.oracle_pixel_alt_count.restype = ctypes.c_int
+    alt = int(L.oracle_pixel_alt_count())
+    out = np.zeros((len(ids), alt, 12), np.float32)
+    if len(ids) == 0 or fw["P"] == 0:
+        return out.astype(np.float64)
+    tm, col = fw["a"]["transMat"], fw["a"]["colors"]
+    L.oracle_pixel_alternatives(o._s, _ptr(col if col is not None and col.size else None),
+                                _ptr(tm if tm is not None and tm.size else None), _ptr(fw["a"]["bg"]),
+                                ctypes.c_float(margin), ctypes.c_int(len(ids)), ctypes.c_void_p(ids.ctypes.data), _ptr(out))
+    return out.astype(np.float64)
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """dsr/rasterize_points.cu:235-254"""
     m = _f32(means3D)

@@ -1012,6 +1012,133 @@ void oracle_pixel_margins(const OracleState *s, const float *transMats, float *o
     }
 }
 
+/* The (pixel, Gaussian) pairs whose SKIP decision (forward.cu:378 depth >= near, :391 alpha >= 1/255) sits within
+ * `margin` (relative, as in oracle_pixel_margins) of its threshold and is reached before the pixel stops.  Taken the other
+ * way such a decision adds or removes one blended splat of weight ~T/255: invisible in the outputs below a few list
+ * positions, but it is the WHOLE contribution of that pixel to that Gaussian's gradient rows (tests/common.py).
+ * Returns the number of pairs; the first min(count, max_n) are stored (order unspecified). */
+long oracle_skip_suspects(const OracleState *s, const float *transMats, float margin, long max_n, int64_t *out_pix,
+                          int32_t *out_gid) {
+    const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+    if (!transMats) transMats = s->transMat;
+    long count = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int tx = tile % gx, ty = tile / gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++) for (int lx = 0; lx < BLOCK_X; lx++) {
+            int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+            if (px >= W || py >= H) continue;
+            float pxf = (float)px, pyf = (float)py;
+            float T = 1.0f;
+            for (uint32_t i = r0; i < r1; i++) {
+                uint32_t id = s->point_list[i];
+                const float *no = s->normal_opacity + 4 * (size_t)id;
+                PairEval e;
+                memset(&e, 0, sizeof e);
+                int ok = eval_pair(pxf, pyf, s->means2D + 2 * (size_t)id, transMats + 9 * (size_t)id, no[3], &e);
+                if (e.pz != 0.0f) {
+                    float m = fabsf(e.depth - near_n) / near_n;
+                    if (e.depth >= near_n) {
+                        float a = no[3] * expf(-0.5f * fminf(e.rho3d, e.rho2d));
+                        m = fminf(m, fabsf(a - 1.0f / 255.0f) * 255.0f);
+                    }
+                    if (m < margin) {
+                        long k;
+#pragma omp atomic capture
+                        k = count++;
+                        if (k < max_n) { out_pix[k] = (int64_t)W * py + px; out_gid[k] = (int32_t)id; }
+                    }
+                }
+                if (!ok) continue;
+                float test_T = T * (1 - e.alpha);
+                if (test_T < 0.0001f) break;
+                T = test_T;
+            }
+        }
+    }
+    return count;
+}
+
+/* What a pixel looks like when its near-threshold decisions fall the other way (tests/common.py: the check on flipped
+ * pixels).  The forward loop of render_fwd is walked again for each of the n pixels in pix_ids, 2^PIXEL_ALT_BITS times:
+ * in walk b, the d-th decision met that sits within `margin` (relative) of its threshold -- the same three kinds and the
+ * same distances as oracle_pixel_margins -- is taken the OTHER way if bit d of b is set (d < PIXEL_ALT_BITS; later ones
+ * are taken as computed).  Walk 0 is the frame as rendered.  out[(k * ALT + b) * 12 + m]: m = 0..2 colour, 3..9 the
+ * seven `others` maps, 10 = last contributor's Gaussian id (-1: none), 11 = median contributor's Gaussian id (-1). */
+#define PIXEL_ALT_BITS 4
+int oracle_pixel_alt_count(void) { return 1 << PIXEL_ALT_BITS; }
+void oracle_pixel_alternatives(const OracleState *s, const float *features, const float *transMats, const float *bg,
+                               float margin, int n, const int64_t *pix_ids, float *out) {
+    const int W = s->W, gx = s->tiles_x;
+    const float mscale = far_n / (far_n - near_n);
+    const int ALT = 1 << PIXEL_ALT_BITS;
+    if (!transMats) transMats = s->transMat;
+    if (!features) features = s->rgb;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int k = 0; k < n; k++) {
+        const int px = (int)(pix_ids[k] % W), py = (int)(pix_ids[k] / W);
+        const int tile = (py / BLOCK_Y) * gx + px / BLOCK_X;
+        const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        const float pxf = (float)px, pyf = (float)py;
+        for (int b = 0; b < ALT; b++) {
+            int d = 0;  /* near-threshold decisions met so far in this walk */
+            float T = 1.0f;
+            float C[3] = {0, 0, 0}, Nn[3] = {0, 0, 0};
+            float Dd = 0, M1 = 0, M2 = 0, distortion = 0, median_depth = 0;
+            long last_id = -1, median_id = -1;
+#define FLIP_IF_CLOSE(decision, dist) do { if ((dist) < margin) { if (d < PIXEL_ALT_BITS && ((b >> d) & 1)) (decision) = !(decision); d++; } } while (0)
+            for (uint32_t i = r0; i < r1; i++) {
+                uint32_t id = s->point_list[i];
+                const float *no = s->normal_opacity + 4 * (size_t)id;
+                PairEval e;
+                memset(&e, 0, sizeof e);
+                eval_pair(pxf, pyf, s->means2D + 2 * (size_t)id, transMats + 9 * (size_t)id, no[3], &e);
+                if (e.pz == 0.0f) continue;  /* exact on every side */
+                /* forward.cu:378 depth >= near, :391 alpha >= 1/255 (eval_pair leaves depth, rho3d, rho2d behind even
+                 * where it rejected the pair) */
+                int near_ok = !(e.depth < near_n);
+                FLIP_IF_CLOSE(near_ok, fabsf(e.depth - near_n) / near_n);
+                if (!near_ok) continue;
+                float G = expf(-0.5f * fminf(e.rho3d, e.rho2d));
+                float alpha = fminf(0.99f, no[3] * G);
+                int alpha_ok = !(alpha < 1.0f / 255.0f);
+                FLIP_IF_CLOSE(alpha_ok, fabsf(no[3] * G - 1.0f / 255.0f) * 255.0f);
+                if (!alpha_ok) continue;
+                float depth = e.depth;
+                float test_T = T * (1 - alpha);
+                int go_on = !(test_T < 0.0001f);
+                FLIP_IF_CLOSE(go_on, fabsf(test_T - 0.0001f) / 0.0001f);
+                if (!go_on) break;
+                float w = alpha * T;
+                float A = 1 - T;
+                float m = mscale * (1 - near_n / depth);
+                distortion += (m * m * A + M2 - 2 * m * M1) * w;
+                Dd += depth * w;
+                M1 += m * w;
+                M2 += m * m * w;
+                int front = T > 0.5f;
+                FLIP_IF_CLOSE(front, fabsf(T - 0.5f) / 0.5f);
+                if (front) { median_depth = depth; median_id = (long)id; }
+                for (int ch = 0; ch < 3; ch++) Nn[ch] += no[ch] * w;
+                for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * (size_t)id + ch] * w;
+                T = test_T;
+                last_id = (long)id;
+            }
+#undef FLIP_IF_CLOSE
+            float *o = out + ((size_t)k * ALT + b) * 12;
+            for (int ch = 0; ch < 3; ch++) o[ch] = C[ch] + T * bg[ch];
+            o[3 + DEPTH_OFFSET] = Dd;
+            o[3 + ALPHA_OFFSET] = 1 - T;
+            for (int ch = 0; ch < 3; ch++) o[3 + NORMAL_OFFSET + ch] = Nn[ch];
+            o[3 + MIDDEPTH_OFFSET] = median_depth;
+            o[3 + DISTORTION_OFFSET] = distortion;
+            o[10] = (float)last_id;
+            o[11] = (float)median_id;
+        }
+    }
+}
+
 /* knn/simple_knn.cu:131-183 for a SUBSET of query points (all P points are candidates): lets the parity
  * test check distCUDA2 at 3e5 .. 1.5e6 points against the brute-force definition on a few thousand queries. */
 void oracle_knn_queries(int P, const float *points, int nq, const int *queries, float *meanDists /*nq*/) {

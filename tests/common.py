@@ -125,7 +125,11 @@ def rel_err(a, b):
 # tools/parity_report.py, profiles/r02_parity_report.txt): they are what the tests assert, so that a regression
 # of one order of magnitude is caught long before the contract is at risk.
 #
-# (max_flipped_frac = 2e-5 of the frame: about twice what S2 / S3 / S5 show -- 5e-6 / 9e-6 / 1e-5.)
+# (max_flipped_frac = 4e-5 of the frame: about twice what S2 / S3 / S5 show since round 5 -- 5e-6 / 1.8e-5 / 2e-5.  Until
+# round 4 the HIP path shared the oracle's arithmetic up to one v_rcp_f32 and one v_exp_f32 per pair (~3e-7 relative in
+# alpha) and flipped 9e-6 of S3's pixels; the affine ray-splat intersection of round 5 (csrc/g4s_device.h) is a different,
+# equally accurate single-precision evaluation of the same quantity, ~1e-6 relative from the oracle's, and flips twice as
+# many of the pixels that sit within MARGIN of a threshold.)
 # A pixel or gradient row outside a bar is accepted ONLY if it is *explained*: the oracle reports, per pixel,
 # how close each discrete decision of the forward loop (alpha >= 1/255, depth >= near, T(1-alpha) >= 1e-4,
 # T > 0.5) came to its threshold (oracle.pixel_margins).  Any two correct single-precision evaluations differ
@@ -136,7 +140,8 @@ OUT_ATOL_GUARD = 2e-5    # guard: measured <= 2.9e-6 on S1..S5 and 60 fuzz scene
 GRAD_RTOL_GUARD = 1e-4   # guard: measured <= 1.1e-5 tensor-level (typically 1e-6)
 ROW_RTOL_GUARD = 1e-2    # guard, row-level (measured <= 8.6e-4): |a-b|_row,inf / |b|_row,inf for rows above ROW_FLOOR of the tensor's max
 ROW_FLOOR = 1e-3
-MARGIN = 1e-5            # relative distance to a decision threshold below which either side is correct
+MARGIN = 4e-5            # relative distance to a decision threshold below which either side is correct: the bound the
+                         # REC_AFFINE certificate puts on the affine form's alpha (AFFINE_TOL, csrc/g4s_device.h); 1e-5 until round 4
 
 
 def _last_and_median_ids(n_contrib, ranges, ids, W, H):
@@ -188,10 +193,37 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False):
     rep["flipped_pixels"] = int(flipped.sum())
     rep["flipped_worst"] = float(dmax[flipped].max()) if flipped.any() else 0.0
     rep["flipped_max_margin"] = float(margins.min(axis=0)[flipped].max()) if flipped.any() else 0.0
+    # A flipped pixel is not exempt either (verdict r4 item 4a: only their NUMBER used to be capped, not their size): the
+    # oracle renders the pixel again with its near-threshold decisions -- a skip, a stop, a median move -- taken the other
+    # way, in every combination (oracle.pixel_alternatives), and the HIP pixel must equal ONE of those renderings: all
+    # ten maps within the guard bar and the same last / median contributor.  flipped_alt_err = the worst distance to the
+    # best-matching alternative; flipped_unmatched = flipped pixels whose contributor ids match no alternative.
+    rep["flipped_alt_err"], rep["flipped_unmatched"] = 0.0, 0
+    if flipped.any():
+        fidx = np.nonzero(flipped)[0]
+        alt = oracle_mod.pixel_alternatives(orc, fidx, MARGIN)                      # [n, ALT, 12]
+        hv = np.concatenate([h["color"].reshape(3, N), h["others"].reshape(7, N)], 0)[:, fidx].T.astype(np.float64)  # [n, 10]
+        d = np.abs(alt[:, :, :10] - hv[:, None, :])
+        if scale_aware:
+            d = d / np.maximum(1.0, mag)[None, None, :]
+        d = d.max(axis=2)                                                            # [n, ALT]
+        if st is not None:
+            ids_ok = (alt[:, :, 10] == hid[0][fidx][:, None]) & (alt[:, :, 11] == hid[1][fidx][:, None])
+            rep["flipped_unmatched"] = int((~ids_ok.any(axis=1)).sum())
+            d = np.where(ids_ok, d, np.inf)
+        best = d.min(axis=1)
+        rep["flipped_alt_err"] = float(best[np.isfinite(best)].max()) if np.isfinite(best).any() else 0.0
     # ---- gradients: a flipped pixel moves O(|cotangent|) between the Gaussians of its tile's list
     if "grads" in h and "grads" in o:
         P = inp["means3D"].shape[0]
         explained = np.zeros(P, bool)
+        # A skip decision (alpha vs 1/255, depth vs near) within MARGIN of its threshold adds or removes ONE blended splat of
+        # weight ~T/255 at that pixel: mostly invisible in the outputs (so the pixel is not among the `flipped` ones), but it
+        # is that pixel's whole contribution to that Gaussian's gradient rows -- several per cent of a row that only a few
+        # pixels feed.  Those Gaussians are explained too, and their pixels join the masked comparison below.
+        sk_pix, sk_gid = oracle_mod.skip_suspects(orc, MARGIN)
+        explained[sk_gid] = True
+        rep["skip_suspect_pairs"] = int(len(sk_pix))
         if flipped.any():
             tiles_x = (W + 15) // 16
             fy, fx = np.divmod(np.nonzero(flipped)[0], W)
@@ -224,11 +256,14 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False):
         # of the flipped pixels set to zero on BOTH sides every row -- the "explained" ones too -- must meet the same
         # bars: what remains unchecked is exactly the contribution of the (capped number of) flipped pixels themselves.
         rep["grads_masked"] = None
-        if flipped.any() and "cot" in h and "cot" in o:
+        masked = flipped.copy()
+        masked[sk_pix] = True
+        rep["masked_pixels"] = int(masked.sum())
+        if masked.any() and "cot" in h and "cot" in o:
             gc = np.array(h["cot"][0], np.float32, copy=True).reshape(3, N)
             go = np.array(h["cot"][1], np.float32, copy=True).reshape(7, N)
-            gc[:, flipped] = 0.0
-            go[:, flipped] = 0.0
+            gc[:, masked] = 0.0
+            go[:, masked] = 0.0
             cot2 = (gc.reshape(3, H, W), go.reshape(7, H, W))
             hm = hip_backward_again(h, inp, cot2)
             om = orc.rasterize_gaussians_backward(cot2[0], cot2[1])
@@ -250,7 +285,7 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False):
 
 
 def assert_parity(h, o, inp, oracle_mod, tag="", out_atol=OUT_ATOL_GUARD, grad_rtol=GRAD_RTOL_GUARD,
-                  row_rtol=ROW_RTOL_GUARD, max_flipped_frac=2e-5, scale_aware=False):
+                  row_rtol=ROW_RTOL_GUARD, max_flipped_frac=4e-5, scale_aware=False):
     """The parity gate of the GPU tests: exact integers, guard bars on everything that is not explained by a
     decision threshold, and a cap on how much may be explained away."""
     assert h["R"] == o["R"], tag
@@ -260,6 +295,8 @@ def assert_parity(h, o, inp, oracle_mod, tag="", out_atol=OUT_ATOL_GUARD, grad_r
     assert rep["out_err_unexplained"] <= out_atol, (tag, "output beyond the bar on a pixel that is on no threshold", rep)
     assert rep["id_mismatch_unexplained"] == 0, (tag, "contributor mismatch on a pixel that is on no threshold", rep)
     assert rep["flipped_pixels"] <= max(2, max_flipped_frac * N), (tag, "too many threshold flips", rep)
+    assert rep["flipped_unmatched"] == 0, (tag, "a flipped pixel's contributors match none of the oracle's alternatives", rep)
+    assert rep["flipped_alt_err"] <= out_atol, (tag, "a flipped pixel is not the oracle's pixel with the decision taken the other way", rep)
     for name, g in rep.get("grads", {}).items():
         assert g["rel_unexplained"] <= grad_rtol, (tag, name, g)
         assert g["row_rel_unexplained"] <= row_rtol, (tag, name, g)

@@ -154,3 +154,54 @@ def test_backward_is_a_sum_of_per_pixel_contributions(oracle_mod):
         full = o["grads"][k].astype(np.float64)
         np.testing.assert_allclose(a[k].astype(np.float64) + b[k].astype(np.float64), full,
                                    atol=2e-5 * (np.abs(full).max() + 1e-30), rtol=0)
+
+
+def test_pixel_alternatives_restate_the_forward_loop():
+    """oracle.pixel_alternatives (the parity gate's check on threshold-flipped pixels, tests/common.py): slot 0 -- no
+    decision flipped -- is the frame as rendered, bit for bit, contributor ids included; with a margin so wide that
+    every decision counts as "close", other slots differ from it (a blended splat skipped, an early stop, ...)."""
+    import numpy as np
+    from common import run_oracle, scene_inputs, _last_and_median_ids
+    from oracle import oracle as om
+
+    inp = scene_inputs(P=3000, W=96, H=64, seed=21, D=2, bg=(0.2, 0.5, 0.1), scale_mul=2.0)
+    o = run_oracle(om, inp)
+    orc = o["oracle"]
+    N = 96 * 64
+    pix = np.arange(0, N, 7)
+    alt = om.pixel_alternatives(orc, pix, 1e-5)
+    want = np.concatenate([o["color"].reshape(3, N), o["others"].reshape(7, N)], 0)[:, pix].T
+    np.testing.assert_array_equal(alt[:, 0, :10].astype(np.float32), want)
+    ids = _last_and_median_ids(orc.state("n_contrib"), orc.state("ranges"), orc.state("point_list"), 96, 64)
+    np.testing.assert_array_equal(alt[:, 0, 10], ids[0][pix])
+    np.testing.assert_array_equal(alt[:, 0, 11], ids[1][pix])
+    # nothing is within 1e-5 of a threshold in most pixels: all slots equal slot 0 there
+    margins = om.pixel_margins(orc).min(axis=0)[pix]
+    far = margins > 1e-5
+    assert far.sum() > 0.9 * len(pix)
+    assert np.all(alt[far] == alt[far][:, :1])
+    wide = om.pixel_alternatives(orc, pix, 1e30)
+    covered = want[:, 4] > 0.05  # pixels something was blended into
+    # (only the first four decisions of a walk can be flipped, and most of those concern splats that miss the pixel anyway)
+    assert np.any(wide[covered][:, 1:, :10] != wide[covered][:, :1, :10], axis=(1, 2)).mean() > 0.3
+
+
+def test_skip_suspects_are_the_pixels_of_the_skip_margin_map():
+    """oracle.skip_suspects lists every (pixel, Gaussian) pair whose skip decision is within the margin of its threshold:
+    its pixels are exactly those where oracle.pixel_margins' skip row is below the margin, and every listed Gaussian is on
+    that pixel's tile list."""
+    import numpy as np
+    from common import run_oracle, scene_inputs
+    from oracle import oracle as om
+
+    inp = scene_inputs(P=3000, W=96, H=64, seed=21, D=2, bg=(0.2, 0.5, 0.1), scale_mul=2.0)
+    orc = run_oracle(om, inp)["oracle"]
+    for margin in (1e-3, 5e-2):
+        pix, gid = om.skip_suspects(orc, margin)
+        want = np.nonzero(om.pixel_margins(orc)[0] < margin)[0]
+        assert len(pix) >= len(want) > 0
+        np.testing.assert_array_equal(np.unique(pix), want)
+        plist, rng = orc.state("point_list"), orc.state("ranges")
+        for p, g in list(zip(pix, gid))[:200]:
+            t = (p // 96 // 16) * 6 + (p % 96) // 16
+            assert g in plist[rng[t, 0]:rng[t, 1]]

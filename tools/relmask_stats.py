@@ -35,8 +35,9 @@ f32 = np.float32
 def region_miss(qx, qy, size):
     """blend.hip quad_misses_box || quad_misses_region for the square [qx, qx+size] x [qy, qy+size] (float32 arithmetic)."""
     x1, y1 = qx + f32(size), qy + f32(size)
-    box = rec[:, 20:24]
-    miss_box = (box[:, 0] > x1) | (box[:, 2] < qx) | (box[:, 1] > y1) | (box[:, 3] < qy)
+    bw = rec[:, 20:24].copy().view(np.uint32)  # bounds in 8x8-pixel quadrants: x0, x1, -, y0 | y1 << 16 (g4s_internal.h)
+    bx0, bx1, by0, by1 = (8 * bw[:, 0]).astype(f32), (8 * bw[:, 1] + 7).astype(f32), (8 * (bw[:, 3] & 0xFFFF)).astype(f32), (8 * (bw[:, 3] >> 16) + 7).astype(f32)
+    miss_box = (bx0 > x1) | (bx1 < qx) | (by0 > y1) | (by1 < qy)
     cx, cy = rec[:, 0], rec[:, 1]
     ddx = np.maximum(np.maximum(qx - cx, cx - x1), f32(0)); ddy = np.maximum(np.maximum(qy - cy, cy - y1), f32(0))
     in_disk = ddx * ddx + ddy * ddy <= rec[:, 30]
