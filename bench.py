@@ -49,7 +49,12 @@ WORKLOADS = {
     "s2": (300_000, 1200, 680, 3, 8),      # Replica-room0-like, configs[1]/[3]
     "s1": (10_000, 256, 256, 3, 1),        # configs[0]
     "s5": (3_000_000, 1200, 680, 3, 8),    # DeepBlending-like, configs[4]
+    # S3 with a TRAINED distribution (verdict r4 item 5): the room re-learnt from its own renders through the product's
+    # training path for 1 000 iterations of the reference's densify / prune / SH / opacity-reset schedule
+    # (g4splat_amd/trained_scene.py); the surfel count is what the training leaves (about 1.5 M)
+    "s3t": (1_500_000, 1600, 1200, 3, 8),
 }
+TRAINED_INFO = {}      # workload -> what trained_scene.scene_trained reported (printed under config.trained_scene)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024           # 256 CUs x 4 SIMDs
 STRONG_VIEWS = 8       # C4 = 8 training views per optimiser step over 1/2/4/8 GPUs
@@ -106,6 +111,12 @@ def build_scene(name, device):
     if name == "s1":
         scene, cam = synthetic.scene_random(P, seed=0, width=W, height=H)
         cams = [cam]
+    elif name == "s3t":
+        from g4splat_amd import trained_scene
+        scene, TRAINED_INFO["s3t"] = trained_scene.scene_trained(seed=0, iters=1000, P=P, width=W, height=H, nviews=nviews,
+                                                                 device=device)
+        P = int(scene.means3D.shape[0])
+        cams = synthetic.room_cameras(nviews, W, H, fovx_deg=90.0)
     else:
         scene = synthetic.scene_room(P, seed=0)
         cams = synthetic.room_cameras(nviews, W, H, fovx_deg=90.0)
@@ -476,6 +487,7 @@ def main():
     timing = not args.no_kernel_timing
     lib.g4s_profile_reset()
     mem0 = torch.cuda.memory_stats(device)
+    exchange_allocs0 = getattr(reducer, "allocations", None)  # (re)allocations of the exchange's buffers up to here
 
     def timed_steps(with_events):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; one HIP event on the launch stream
@@ -605,7 +617,16 @@ def main():
         units, inst = int(uu[0].item()), int(uu[1].item())
 
     exchange_info = None
+    replicas_identical = None
     if dist is not None:
+        # After the last exchange every rank must hold the SAME BITS in its gradient bucket (the owners' sums gathered
+        # everywhere): two checksums of the bit patterns, compared across the ranks.
+        bits = bucket.view(torch.int32).to(torch.int64)
+        weights = torch.arange(bits.numel(), device=device, dtype=torch.int64) % 1021 + 1
+        mine = torch.stack([bits.sum(), (bits * weights).sum()])
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        replicas_identical = all(bool(torch.equal(e, everyone[0])) for e in everyone)
         try:
             rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:
@@ -628,6 +649,10 @@ def main():
             "bytes_per_rank": dict(getattr(reducer, "last_bytes", {})) or None,
             "rows_sent_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows else None),
             "buffer_allocations": getattr(reducer, "allocations", None),
+            # persistent buffers: nothing of the exchange is (re)allocated once the warm-up is over
+            "buffer_allocations_after_warmup": (getattr(reducer, "allocations") - exchange_allocs0
+                                                if exchange_allocs0 is not None else None),
+            "replicas_identical": replicas_identical,
         }
 
     if rank != 0:
@@ -773,10 +798,12 @@ def main():
         "value": units / (args.steps * step_ms * 1e-3), "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {P} surfels (room box), {W}x{H}, SH degree {D}, {len(dcams)} views, "
+        "config": {"workload": f"{args.workload}: {P} surfels (room box" + (", re-learnt: trained distribution" if args.workload in TRAINED_INFO else "")
+                               + f"), {W}x{H}, SH degree {D}, {len(dcams)} views, "
                                + (f"{STRONG_VIEWS} views per step over {world} GPU(s): {views_per_rank} per GPU, accumulated "
                                   f"locally ({min(3, views_per_rank)} in flight)" if strong else "1 view/GPU/step"),
                    "P": P, "width": W, "height": H,
+                   "trained_scene": TRAINED_INFO.get(args.workload),
                    "sh_degree": D, "visible_per_view": round(units / args.steps / world / views_per_rank),
                    "instances_per_view": round(inst / args.steps / world / views_per_rank),
                    "views_per_step": world * views_per_rank,

@@ -19,7 +19,7 @@ c_sz = ctypes.c_size_t
 class G4sLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "rec", "clamped", "depth_sorted", "tiles_touched", "geom_bytes", "entries", "qhit", "binning_bytes", "ranges",
-        "final_T", "n_contrib", "tile_order", "image_bytes")]
+        "final_T", "n_contrib", "tile_order", "image_bytes", "hot_count")]
 
 
 # symbol -> (restype, argtypes); tests/test_abi.py checks this table against include/g4s_rasterizer.h

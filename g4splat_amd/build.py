@@ -35,6 +35,18 @@ PYBIND_DIR = os.path.join(_HERE, "pybind")
 PYBIND_SO = os.path.join(PYBIND_DIR, "_C_pybind.so")
 
 
+def _rocm_path():
+    """ROCM_PATH / ROCM_HOME if set, else the root of the hipcc on PATH, else /opt/rocm."""
+    import shutil
+    for k in ("ROCM_PATH", "ROCM_HOME"):
+        if os.environ.get(k):
+            return os.environ[k]
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        return os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    return "/opt/rocm"
+
+
 def build_pybind(force=False, verbose=False):
     """INTEGRATION.md section B, compiled: the pybind module a maintainer of the reference would build in place of its
     CUDA extension -- pybind/rasterize_points.cpp + pybind/ext.cpp, plain C++ through torch.utils.cpp_extension (explicit
@@ -52,7 +64,7 @@ def build_pybind(force=False, verbose=False):
         name="_C_pybind", sources=srcs[:2], build_directory=PYBIND_DIR, verbose=verbose, with_cuda=False,
         is_python_module=False,  # only build here; pybind_module() below imports the file
         extra_cflags=["-O2", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1"],
-        extra_include_paths=[os.path.abspath(os.path.join(_HERE, "..", "include")), "/opt/rocm/include"],
+        extra_include_paths=[os.path.abspath(os.path.join(_HERE, "..", "include")), os.path.join(_rocm_path(), "include")],
         extra_ldflags=[f"-L{_HERE}", "-lg4s_hip", "-Wl,-rpath,'$$ORIGIN/..'", "-lc10_hip", "-ltorch_hip"])
     if not os.path.exists(PYBIND_SO):
         raise RuntimeError("building the pybind stub failed: " + PYBIND_SO + " not produced")

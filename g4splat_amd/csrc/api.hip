@@ -218,6 +218,7 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     out->n_contrib = im.n_contrib;
     out->tile_order = im.tile_order;
     out->image_bytes = im.bytes;
+    out->hot_count = im.hot_count;
     return G4S_OK;
 }
 

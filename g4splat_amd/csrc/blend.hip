@@ -25,11 +25,14 @@
 
 namespace g4s {
 
-// true if the 8x8 pixel quadrant (kx, ky) -- pixels [8 kx, 8 kx + 7] x [8 ky, 8 ky + 7] -- misses the splat's alpha-cutoff
-// box (record quad 5: quadrant bounds, g4s_internal.h)
-__device__ __forceinline__ bool quad_misses_box(const float4 q5, uint32_t kx, uint32_t ky) {
+// Which of the tile's four 8x8-pixel quadrants -- columns 2 tile_x + {0, 1}, rows 2 tile_y + {0, 1} -- the splat's
+// alpha-cutoff box reaches (record quad 5: quadrant bounds, g4s_internal.h): bit q = quadrant (q & 1, q >> 1).
+__device__ __forceinline__ uint32_t quads_in_box(const float4 q5, uint32_t kx0, uint32_t ky0) {
     const uint32_t x0 = __float_as_uint(q5.x), x1 = __float_as_uint(q5.y), yw = __float_as_uint(q5.w);
-    return kx < x0 || kx > x1 || ky < (yw & 0xFFFFu) || ky > (yw >> 16);
+    const uint32_t y0 = yw & 0xFFFFu, y1 = yw >> 16;
+    const uint32_t cols = (kx0 >= x0 && kx0 <= x1 ? 1u : 0u) | (kx0 + 1 >= x0 && kx0 + 1 <= x1 ? 2u : 0u);
+    const uint32_t rows = (ky0 >= y0 && ky0 <= y1 ? 1u : 0u) | (ky0 + 1 >= y0 && ky0 + 1 <= y1 ? 2u : 0u);
+    return ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
 }
 
 // true if no pixel of the quadrant can pass the alpha test: the quadrant rectangle [qx, qx+7] x [qy, qy+7] meets
@@ -153,11 +156,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
             for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][threadIdx.x] = rq[i];
             // Which of the tile's four quadrants can this splat reach at all?  Decided ONCE per staged entry (not
             // once per quadrant wave): bounding box first, then the exact region (low-pass disk + cutoff ellipse).
+            const uint32_t inbox = quads_in_box(rq[5], 2u * (uint32_t)tile_x, 2u * (uint32_t)tile_y);
             uint32_t relmask = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int bxi = tile_x * TILE + (q & 1) * 8, byi = tile_y * TILE + (q >> 1) * 8;
-                bool rel = !quad_misses_box(rq[5], (uint32_t)(bxi >> 3), (uint32_t)(byi >> 3));
+                bool rel = (inbox >> q) & 1u;
                 if (rel && !a.box_only) rel = !quad_misses_region(rq[0], rq[6], rq[7], (float)bxi, (float)byi);
                 relmask |= rel ? (1u << q) : 0u;
             }

@@ -314,8 +314,12 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, F3 pos, F3 c
 // box (record quad 5) and accumulates the reference's instance count (num_rendered).
 // SH_MODE: 0 = packed [P,16,3] on a 16-byte aligned base (quad loads), 1 = packed generic, 2 = split (dc / rest).
 // One instantiation per layout: a runtime switch inside one kernel costs the common layout ~20 % (register copies at the joins).
+// 5 waves per SIMD (96 VGPRs, three 4-byte spills) instead of the 4 that the compiler's own 100 registers allow: the kernel
+// is bound by the latency of its per-workgroup chain (loads -> cull -> the double-precision tail of the 28 % of the lanes
+// that bin something), and a fifth resident wave hides some of it: 0.107 -> 0.102 ms (profiles/r05_ab_k1_occupancy.txt).
+// (6 waves = 80 VGPRs spill 80 registers: 0.125 ms, LAB_NOTES section 3.)
 template <int SH_MODE>
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) preprocess_fwd_kernel(PreprocessArgs a) {
     const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
     const bool in_range = idx < a.P;
     int radius_out = 0;
@@ -947,9 +951,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             const double ld[3] = {(double)cy * Tw.x - Tv.x, (double)cy * Tw.y - Tv.y, (double)cy * Tw.z - Tv.z};
             const double det = (kd[1] * ld[2] - kd[2] * ld[1]) * Tw.x + (kd[2] * ld[0] - kd[0] * ld[2]) * Tw.y +
                                (kd[0] * ld[1] - kd[1] * ld[0]) * Tw.z;
-            const double inv_det = 1.0 / det;  // (REC_AFFINE: det(T) is invertible)
-            const float gam = (float)inv_det;
-            const float gdet = (float)((double)Zd * inv_det);
+            const float gam = 1.0f / (float)det;  // (REC_AFFINE: det(T) is invertible; one single-precision division, not a double one)
+            const float gdet = Zd * gam;
             const F3 u1 = crs(Y, Tw), u2 = crs(S, lc), v1 = crs(Tw, X), v2 = crs(kc, S), w1 = crs(lc, X), w2 = crs(Y, kc);
             const F3 U = mk3(gam * (u1.x + u2.x), gam * (u1.y + u2.y), gam * (u1.z + u2.z));
             const F3 V = mk3(gam * (v1.x + v2.x), gam * (v1.y + v2.y), gam * (v1.z + v2.z));

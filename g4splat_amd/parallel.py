@@ -295,12 +295,16 @@ class OwnerReduce:
             # per-owner counts: the list is sorted, so owner d's rows are the range between two binary searches (a
             # scatter_add of 1.5 M ones onto 8 counters would serialise on them)
             pos = torch.searchsorted(self._idx, self._edges)
+            if getattr(self, "debug_checks", False):
+                self._visible_last = visible.clone()
             meta = self._meta
             # per row: the radius in the low 30 bits and "visible on this rank" in bit 30 -- after the MAX, bit 30 is the
             # union of the ranks' visible sets whatever the radii are, and the low bits are the largest radius among the
             # ranks that see the row (the others hold 0)
             if radii is not None:
-                meta[:self.P].copy_(radii)
+                # (radii only where the rank sees the row: a row with radii > 0 but visible == False would otherwise lose
+                # the MAX against another rank's 2^30 + smaller radius -- ADVICE r4)
+                torch.mul(radii.to(torch.int32), visible.to(torch.int32), out=meta[:self.P])
                 meta[:self.P].bitwise_or_(visible.to(torch.int32) << 30)
             else:
                 torch.mul(visible.to(torch.int32), 1 << 30, out=meta[:self.P])
@@ -386,10 +390,23 @@ class OwnerReduce:
     # ---- second half: rows to their owners, owners accumulate, (optionally) everybody gets every shard ------------
     def finish(self, gather: bool = True):
         """Reduces the rows in place.  gather=True: on return every row view holds the sum over all ranks.
-        gather=False: only this rank's own rows [bounds()) do (what an owner-applied optimiser needs)."""
+        gather=False: only this rank's own rows [bounds()) do (what an owner-applied optimiser needs).
+
+        PRECONDITION: a row this rank did not flag `visible` in begin() holds zeros here (what the rasterizer's backward
+        leaves: every gradient of a Gaussian with radii == 0 is zero).  Only visible rows travel to their owners, and the
+        sparse gather writes back only rows that SOME rank flagged -- a non-zero value in an unflagged row (a regulariser
+        over all Gaussians added to .grad before the exchange, say) would neither be summed nor overwritten, and the
+        replicas would drift apart silently.  Flag such rows visible, or set `debug_checks = True` to have every finish()
+        verify the precondition (one reduction and a host read-back per call: for bring-up, not for the step)."""
         if not self._pending:
             raise RuntimeError("OwnerReduce.finish() without begin()")
         self._pending = False
+        if getattr(self, "debug_checks", False):
+            hidden = ~self._visible_last
+            bad = sum(int((r[hidden] != 0).any().item()) for r in self.rows)
+            if bad:
+                raise RuntimeError(f"OwnerReduce.finish(): {bad} of the row tensors hold non-zero values in rows that were "
+                                   "not flagged visible in begin()")
         if self._event is not None:
             self._event.synchronize()  # recorded a whole backward ago: returns at once
         torch.bitwise_and(self._meta[:self.P], (1 << 30) - 1, out=self._max_radii)  # (the next begin() reuses _meta)
@@ -671,7 +688,9 @@ class ViewParallel:
         self.compact_below = compact_below  # RowSparseAllReduce threshold; 0.0 = always dense
         self._reducer = self._side = None
         self._pipe = self._pipe_key = None  # accumulate(): the ViewPipeline of the current (P, image size)
-        self._capacity = {}
+        self._capacity = {}   # (P, W, H) -> instance capacity of the pipeline's PresizedStates; 0 = unknown: stay sequential
+        self._dirty = False   # something has been accumulated since zero()
+        self.regrown = 0      # accumulate(): steps redone sequentially because a view outgrew the pipeline's capacity
         self.bucket = GradientBucket(params)
         n = self.bucket.params[0].shape[0]
         dev = self.bucket.flat.device
@@ -687,6 +706,7 @@ class ViewParallel:
         """Per-view densification statistics, taken before any reduction."""
         # (no boolean-mask indexing: `x[mask] += ...` reads the count back and would stall a pipelined loop.  The same
         # sums element by element: rows outside the filter get + 0.)
+        self._dirty = True
         g = viewspace_points.grad
         vis = visibility_filter.unsqueeze(1)
         self.grad_norm_sum.add_(torch.where(vis, torch.norm(g, dim=-1, keepdim=True), torch.zeros_like(self.grad_norm_sum)))
@@ -713,11 +733,19 @@ class ViewParallel:
 
         The pipeline's PresizedStates need a bound on the (Gaussian, tile) instances of a view: `instance_capacity`,
         or -- by default -- 1.5 x the largest count seen in the first step at this (P, image size), which therefore runs
-        sequentially through the reference-shaped forward.  A view that exceeds the capacity is invalid:
-        `check_overflow` (one read of the device status words per step) raises."""
+        sequentially through the reference-shaped forward (and every later step does if `view_step` does not go through
+        this package's rasterizer front-end, so that no count is known).  Training draws other cameras every step, and
+        a later view can bin more than that.  Such a view is invalid -- its forward kept only the first `capacity`
+        instances -- and so is everything the step has added to `.grad` and to the statistics behind it: `check_overflow`
+        (one read of the slots' status words per step, every view of the step included) then DISCARDS the step's local
+        sums (zero()), grows the capacity to 1.5 x the count it has just seen, and redoes the step sequentially; the
+        next step rebuilds the pipeline at the new size (`regrown` counts these steps).  That presumes the step's
+        accumulation started in this call: if something was accumulated since zero() before it, there is nothing safe
+        to discard and the overflow raises."""
         views = list(views)
         params = self.bucket.params
         dev = params[0].device
+        fresh = not self._dirty
 
         def plain():
             from . import diff_surfel_rasterization as dsr
@@ -739,9 +767,16 @@ class ViewParallel:
             if self._pipe is not None:
                 self._pipe.release_hooks()
                 self._pipe = None
-            cap = instance_capacity if instance_capacity is not None else self._capacity.get(key[:3])
+            cap = self._capacity.get(key[:3])
+            if instance_capacity is not None:  # (a capacity that has had to grow stays grown)
+                cap = max(int(instance_capacity), cap or 0)
             if cap is None:  # first step at this size: learn the instance counts, view after view
-                self._capacity[key[:3]] = int(plain() * 1.5) + 4096
+                seen = plain()
+                # (0: view_step does not run this package's rasterizer front-end on this thread -- nothing to size by)
+                self._capacity[key[:3]] = int(seen * 1.5) + 4096 if seen > 0 else 0
+                return
+            if cap == 0:
+                plain()
                 return
             self._pipe = ViewPipeline(key[0], W, H, int(cap), dev, k=key[3])
             self._pipe.order_accumulation(params)
@@ -751,15 +786,28 @@ class ViewParallel:
             except AttributeError:
                 pass
         pipe = self._pipe
+        if check_overflow:
+            pipe.reset_peak()
         for j, v in enumerate(views):
             with pipe.slot(j):
                 out = view_step(v)
                 pipe.after_previous_view()
                 self.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
         pipe.join()
-        if check_overflow and pipe.overflowed():
-            raise RuntimeError("ViewParallel.accumulate: a view binned more instances than the pipeline's capacity "
-                               f"({pipe.states[0].capacity}); pass a larger instance_capacity")
+        if check_overflow:
+            seen, over = pipe.peak()
+            if over:
+                if not fresh:
+                    raise RuntimeError("ViewParallel.accumulate: a view binned more instances than the pipeline's capacity "
+                                       f"({pipe.states[0].capacity}) and the step's accumulation did not start in this call; "
+                                       "pass a larger instance_capacity")
+                # discard what the step has accumulated, grow, redo the step one view at a time
+                self.zero()
+                self._capacity[key[:3]] = int(seen * 1.5) + 4096
+                pipe.release_hooks()
+                self._pipe = self._pipe_key = None
+                self.regrown += 1
+                plain()
 
     def all_reduce(self):
         """Sum the gradient bucket (and the statistics) over all ranks.  Returns the reduced statistics."""
@@ -798,6 +846,7 @@ class ViewParallel:
         self.vis_count.zero_()
         self.max_radii.zero_()
         self._visible = None
+        self._dirty = False
 
 
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group: Optional[dist.ProcessGroup] = None):

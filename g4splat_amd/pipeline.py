@@ -63,10 +63,15 @@ class ViewPipeline:
         self._last_done = None
         self._hooks = []
         self._ordered = []  # the leaves of order_accumulation: their .grad buffers must stay persistent
+        # per slot: the element-wise maximum of the status words [num_rendered, binned, emitting, overflow] of every forward
+        # issued in the slot since reset_peak() -- a slot serves several views of a step, and its state's own status word
+        # only remembers the last one
+        self._peak = []
         for s in self.streams:
             with torch.cuda.stream(s):
                 self.states.append(_C.PresizedState(P, width, height, instance_capacity, self.device))
                 self.workspaces.append(torch.empty(ws_bytes, dtype=torch.uint8, device=self.device))
+                self._peak.append(torch.zeros(4, dtype=torch.int32, device=self.device))
         torch.cuda.synchronize(self.device)
 
     @contextlib.contextmanager
@@ -89,6 +94,7 @@ class ViewPipeline:
             try:
                 yield self.states[j], self.workspaces[j]
             finally:
+                torch.maximum(self._peak[j], self.states[j].status, out=self._peak[j])  # (on the slot's stream)
                 self._done[j].record(s)
                 self._last_done = self._done[j]
 
@@ -133,6 +139,18 @@ class ViewPipeline:
         for s in self.streams:
             cur.wait_stream(s)
 
+    def reset_peak(self):
+        """Forgets the status words seen so far (start of a step)."""
+        for j, s in enumerate(self.streams):
+            with torch.cuda.stream(s):
+                self._peak[j].zero_()
+
+    def peak(self):
+        """(largest num_rendered, overflowed) over every forward issued in a slot since reset_peak() -- not only each
+        slot's last one.  Reads the device words: synchronises with the slots' streams."""
+        words = torch.stack(self._peak).cpu()
+        return int(words[:, 0].max()), bool(words[:, 3].max() != 0)
+
     def overflowed(self):
-        """True if some slot's last forward exceeded the instance capacity (reads the device status words: synchronises)."""
-        return any(int(st.status[3].item()) != 0 for st in self.states)
+        """True if a forward issued in some slot since reset_peak() exceeded the instance capacity (synchronises)."""
+        return self.peak()[1]

@@ -5,6 +5,7 @@
 // checks, zero-fill conventions and tuple orders.
 #include "rasterize_points.h"
 
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 
 #include <stdexcept>
@@ -29,6 +30,14 @@ void check_input(const torch::Tensor& t, const char* name) {  // CHECK_INPUT, ra
 torch::Tensor f32(const torch::Tensor& t) { return t.to(torch::kFloat32).contiguous(); }
 const float* fptr(const torch::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
 void* stream_of(const torch::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// The tensors' device becomes current for the call: the library launches on the stream it is handed, and the tensors
+// allocated here must come from that device's pool (a process with several GPUs may have another one current).
+// (the device-generic guard: torch-ROCm registers its HIP guard implementation under the device type "cuda", which is what
+// the tensors report; c10::hip::HIPGuard itself refuses that type)
+struct DeviceOf {
+    c10::OptionalDeviceGuard guard;
+    explicit DeviceOf(const torch::Tensor& t) { if (t.is_cuda()) guard.reset_device(t.device()); }
+};
 
 }  // namespace
 
@@ -40,6 +49,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
                        const int image_width, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
                        const bool prefiltered, const bool debug) {
     if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");
+    const DeviceOf on_device(means3D);
     check_input(background, "background"); check_input(means3D, "means3D"); check_input(colors, "colors");
     check_input(opacity, "opacity"); check_input(scales, "scales"); check_input(rotations, "rotations");
     check_input(transMat_precomp, "transMat_precomp"); check_input(viewmatrix, "viewmatrix");
@@ -75,6 +85,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
                                const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer,
                                const torch::Tensor& imageBuffer, const bool debug) {
+    const DeviceOf on_device(means3D);
     check_input(background, "background"); check_input(means3D, "means3D"); check_input(radii, "radii");
     check_input(colors, "colors"); check_input(scales, "scales"); check_input(rotations, "rotations");
     check_input(transMat_precomp, "transMat_precomp"); check_input(viewmatrix, "viewmatrix");
@@ -112,6 +123,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix) {
     const int P = (int)means3D.size(0);
+    const DeviceOf on_device(means3D);
     torch::Tensor present = torch::zeros({P}, means3D.options().dtype(at::kBool));  // rasterize_points.cu:240-241
     if (P != 0) {
         check_input(means3D, "means3D");

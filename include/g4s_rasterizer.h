@@ -242,7 +242,9 @@ int g4s_knn_mean_dist(int P, const float* points, float* meanDists, char* worksp
  * callbacks.  Not part of the drop-in surface. */
 typedef struct g4s_layout {
     /* geometry chunk */
-    size_t rec;          /* P x 32 floats: xy, inst_off(u32), count(u32), normal, opacity, Tu,Tv,Tw, rgb, box, cutoff ellipse */
+    size_t rec;          /* P x 32 floats: xy, inst_off(u32), count(u32) | bit 31 REC_AFFINE, normal, opacity, Tu,Tv,Tw -- or, for
+                            REC_AFFINE splats, the affine ray-splat intersection A', B', Dc' --, rgb, box, Tw.z, cutoff ellipse
+                            (csrc/g4s_internal.h) */
     size_t clamped;      /* P x u8 (bit c = channel c clamped) */
     size_t depth_sorted; /* u32 indices of the Gaussians that emit instances, in (depth, index) order */
     size_t tiles_touched;/* P x u32 */
@@ -257,6 +259,7 @@ typedef struct g4s_layout {
     size_t n_contrib;    /* 2N u32: last contributor, median contributor */
     size_t tile_order;   /* tiles x u32: workgroup id -> tile, longest instance list first */
     size_t image_bytes;
+    size_t hot_count;    /* (image chunk) u32: tiles the last backward over this state handed to the four-wave kernel */
 } g4s_layout;
 
 int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
@@ -265,7 +268,8 @@ int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_layout* out);
  * set through this call only: the library never reads the environment on a call path.  None of them changes a result
  * beyond rounding (the tests assert exactly that):
  *   "box_only"           forward skips quadrants by the bounding box only, not by the exact cutoff region
- *   "no_fastpath"        every splat takes the general per-pixel evaluation (REC_NO_LOWPASS ignored)
+ *   "no_fastpath"        no splat is certified REC_AFFINE: every (pixel, splat) pair is evaluated with the reference's
+ *                        own arithmetic (results equal the default's to rounding, not bit for bit)
  *   "bwd_fwd_order"      the blend backward walks the tiles in the forward's order
  *   "bwd_hot_threshold"  list depth above which a tile goes to the four-wave backward (G4S_OPTION_UNSET = automatic)
  *   "no_side_zero"       the blend backward does not clear dL_dsh on the side (K8 clears the rows it skips)

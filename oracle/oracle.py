@@ -184,13 +184,16 @@ def pixel_margins(o):
     return out
 
 
-def skip_suspects(o, margin):
+def skip_suspects(o, margin, with_margins=False):
     """(int64[n] flat pixel indices, int32[n] Gaussian ids): the (pixel, Gaussian) pairs of Oracle `o`'s forward whose skip
     decision (alpha vs 1/255, depth vs near) sits within `margin` of its threshold and is reached before the pixel stops.
-    See oracle_skip_suspects in surfel_oracle.c."""
+    with_margins: also pixel_margins(o), from the same walk over the frame.  See oracle_skip_suspects in surfel_oracle.c."""
     fw = o._fw
+    N = fw["H"] * fw["W"]
+    margins = np.full((3, N), np.finfo(np.float32).max, np.float32) if with_margins else None
     if fw["P"] == 0:
-        return np.zeros(0, np.int64), np.zeros(0, np.int32)
+        empty = (np.zeros(0, np.int64), np.zeros(0, np.int32))
+        return empty + (margins,) if with_margins else empty
     tm = fw["a"]["transMat"]
     tmp = _ptr(tm if tm is not None and tm.size else None)
     L = lib()
@@ -199,9 +202,9 @@ def skip_suspects(o, margin):
     while True:
         pix, gid = np.zeros(cap, np.int64), np.zeros(cap, np.int32)
         n = int(L.oracle_skip_suspects(o._s, tmp, ctypes.c_float(margin), ctypes.c_long(cap),
-                                       ctypes.c_void_p(pix.ctypes.data), ctypes.c_void_p(gid.ctypes.data)))
+                                       ctypes.c_void_p(pix.ctypes.data), ctypes.c_void_p(gid.ctypes.data), _ptr(margins)))
         if n <= cap:
-            return pix[:n], gid[:n]
+            return (pix[:n], gid[:n], margins) if with_margins else (pix[:n], gid[:n])
         cap = n
 
 

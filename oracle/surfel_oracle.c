@@ -1018,8 +1018,9 @@ void oracle_pixel_margins(const OracleState *s, const float *transMats, float *o
  * positions, but it is the WHOLE contribution of that pixel to that Gaussian's gradient rows (tests/common.py).
  * Returns the number of pairs; the first min(count, max_n) are stored (order unspecified). */
 long oracle_skip_suspects(const OracleState *s, const float *transMats, float margin, long max_n, int64_t *out_pix,
-                          int32_t *out_gid) {
+                          int32_t *out_gid, float *out_margins /* 3N as oracle_pixel_margins writes them, or NULL */) {
     const int W = s->W, H = s->H, gx = s->tiles_x, gy = s->tiles_y;
+    const size_t N = (size_t)W * H;
     if (!transMats) transMats = s->transMat;
     long count = 0;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -1031,6 +1032,7 @@ long oracle_skip_suspects(const OracleState *s, const float *transMats, float ma
             if (px >= W || py >= H) continue;
             float pxf = (float)px, pyf = (float)py;
             float T = 1.0f;
+            float m0 = FLT_MAX, m1 = FLT_MAX, m2 = FLT_MAX;  /* the three rows of oracle_pixel_margins */
             for (uint32_t i = r0; i < r1; i++) {
                 uint32_t id = s->point_list[i];
                 const float *no = s->normal_opacity + 4 * (size_t)id;
@@ -1043,6 +1045,7 @@ long oracle_skip_suspects(const OracleState *s, const float *transMats, float ma
                         float a = no[3] * expf(-0.5f * fminf(e.rho3d, e.rho2d));
                         m = fminf(m, fabsf(a - 1.0f / 255.0f) * 255.0f);
                     }
+                    if (m < m0) m0 = m;
                     if (m < margin) {
                         long k;
 #pragma omp atomic capture
@@ -1052,8 +1055,16 @@ long oracle_skip_suspects(const OracleState *s, const float *transMats, float ma
                 }
                 if (!ok) continue;
                 float test_T = T * (1 - e.alpha);
+                float mt = fabsf(test_T - 0.0001f) / 0.0001f;
+                if (mt < m1) m1 = mt;
                 if (test_T < 0.0001f) break;
+                float mh = fabsf(T - 0.5f) / 0.5f;
+                if (mh < m2) m2 = mh;
                 T = test_T;
+            }
+            if (out_margins) {
+                size_t pix_id = (size_t)W * py + px;
+                out_margins[pix_id] = m0; out_margins[pix_id + N] = m1; out_margins[pix_id + 2 * N] = m2;
             }
         }
     }

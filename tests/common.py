@@ -108,6 +108,7 @@ def hip_state(out, inp):
     st["final_T"] = img[L.final_T:L.final_T + 12 * N].view(np.float32).reshape(3, N)
     st["n_contrib"] = img[L.n_contrib:L.n_contrib + 8 * N].view(np.uint32).reshape(2, N)
     st["tile_order"] = img[L.tile_order:L.tile_order + 4 * tiles].view(np.uint32)
+    st["hot_count"] = int(img[L.hot_count:L.hot_count + 4].view(np.uint32)[0])  # (of the last backward, if one ran)
     return st
 
 
@@ -166,7 +167,7 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False):
     N = W * H
     orc = o["oracle"]
     rep = dict(N=N, R=int(o["R"]))
-    margins = oracle_mod.pixel_margins(orc)          # [3, N]
+    sk_pix, sk_gid, margins = oracle_mod.skip_suspects(orc, MARGIN, with_margins=True)  # margins [3, N]: one walk for both
     suspect = margins.min(axis=0) < MARGIN           # either side of some threshold is a correct answer here
     rep["suspect_pixels"] = int(suspect.sum())
     # ---- outputs
@@ -221,7 +222,6 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False):
         # weight ~T/255 at that pixel: mostly invisible in the outputs (so the pixel is not among the `flipped` ones), but it
         # is that pixel's whole contribution to that Gaussian's gradient rows -- several per cent of a row that only a few
         # pixels feed.  Those Gaussians are explained too, and their pixels join the masked comparison below.
-        sk_pix, sk_gid = oracle_mod.skip_suspects(orc, MARGIN)
         explained[sk_gid] = True
         rep["skip_suspect_pairs"] = int(len(sk_pix))
         if flipped.any():

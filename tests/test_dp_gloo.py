@@ -212,6 +212,7 @@ def _owner_worker(rank, world, port, q):
         dense = flat.clone()
         dist.all_reduce(dense)
         red = OwnerReduce(rows)
+        red.debug_checks = True      # finish() verifies its precondition: unflagged rows hold zeros
         radii = vis.to(torch.int32) * 5
         red.begin(vis, radii=radii)  # (with the radii the exchange knows the union of the visible sets: sparse gather)
         red.finish()
@@ -231,6 +232,28 @@ def _owner_worker(rank, world, port, q):
         red2.finish()
         gathers.add(red2.last_gather)
         out.append((P, frac, exact, ok, bool(torch.equal(flat, flat2)), red.last_rows_sent, int(vis.sum())))
+    # only the radii of rows a rank FLAGS take part in the MAX (the reference updates max_radii2D under the
+    # visibility filter, train_with_refine_depth.py:583), and debug_checks refuses a non-zero unflagged row
+    P = 64
+    rows = [torch.zeros(P, 3)]
+    vis = torch.zeros(P, dtype=torch.bool)
+    vis[rank::world] = True
+    rows[0][vis] = 1.0
+    radii = torch.full((P,), 3 + rank, dtype=torch.int32)  # also where this rank does not see the row
+    red = OwnerReduce(rows)
+    red.debug_checks = True
+    red.begin(vis, radii=radii)
+    red.finish()
+    want = (torch.arange(P) % world + 3).to(red.max_radii.dtype)  # row i is seen by rank i % world only
+    radii_ok = bool(torch.equal(red.max_radii, want)) and bool(torch.equal(rows[0], torch.ones(P, 3)))
+    rows[0][(rank + 1) % world::world] += 0.5   # a value in a row this rank does not flag
+    red.begin(vis, radii=radii)
+    try:
+        red.finish()
+        refused = False
+    except RuntimeError as e:
+        refused = "not flagged visible" in str(e)
+    out.append((radii_ok, refused))
     out.append(sorted(g for g in gathers if g))
     q.put((rank, out))
     dist.barrier()
@@ -254,7 +277,8 @@ def test_owner_reduce_equals_dense_all_reduce(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        for P, frac, exact, ok, same_again, sent, nvis in res[r][:-1]:
+        assert res[r][-2] == (True, True), res[r][-2]
+        for P, frac, exact, ok, same_again, sent, nvis in res[r][:-2]:
             assert ok, (r, P, frac, exact)
             assert same_again, (r, P, frac)       # (sparse gather with radii == dense gather without: the same bits)
             assert 0 <= sent <= nvis

@@ -304,9 +304,10 @@ def room_inputs(P, W, H, view, nviews, D=3, bg=(0.3, 0.1, 0.2)):
 
 def full_size_case(oracle_mod, capsys, tag, inp, seed=3):
     """One BASELINE-size configuration against the oracle, with the threshold-margin proof: per-Gaussian results
-    and the binning exact; every pixel beyond the guard bar and every contributor-id mismatch must sit within 1e-5
-    (relative) of a decision threshold in the oracle; the number of such pixels is capped at 2e-5 of the frame; and with
-    the cotangents of those pixels zeroed on both sides EVERY gradient row meets the guard bars (no row is exempt)."""
+    and the binning exact; every pixel beyond the guard bar and every contributor-id mismatch must sit within MARGIN
+    (relative) of a decision threshold in the oracle AND equal the oracle's pixel with that decision taken the other way;
+    the number of such pixels is capped at 4e-5 of the frame; and with the cotangents of those pixels (and of the pixels
+    with a near-threshold skip decision) zeroed on both sides EVERY gradient row meets the guard bars (no row is exempt)."""
     gr = cotangents(inp["H"], inp["W"], seed=seed)
     o = run_oracle(oracle_mod, inp, gr)
     h = run_hip(inp, gr)
@@ -321,11 +322,13 @@ def full_size_case(oracle_mod, capsys, tag, inp, seed=3):
         g = rep["grads"]
         gm = rep.get("grads_masked")
         print(f"\n{tag}: R={rep['R']}, PSNR(HIP, oracle) {psnr:.1f} dB; {rep['suspect_pixels']} of {rep['N']} pixels within "
-              f"1e-5 of a threshold, {rep['flipped_pixels']} of them flipped (worst output difference "
-              f"{rep['flipped_worst']:.3g}); elsewhere outputs <= {rep['out_err_unexplained']:.2e}, gradients <= "
+              f"4e-5 of a threshold, {rep['flipped_pixels']} of them flipped (worst output difference "
+              f"{rep['flipped_worst']:.3g}; against the oracle's pixel with the decision taken the other way "
+              f"{rep['flipped_alt_err']:.2e}); elsewhere outputs <= {rep['out_err_unexplained']:.2e}, gradients <= "
               f"{max(v['rel_unexplained'] for v in g.values()):.2e} (tensor) / "
-              f"{max(v['row_rel_unexplained'] for v in g.values()):.2e} (row); with the flipped pixels' cotangents zeroed "
-              f"on both sides ALL rows (incl. the {rep['explained_rows']} in tile lists of flips) <= "
+              f"{max(v['row_rel_unexplained'] for v in g.values()):.2e} (row); with the cotangents of the "
+              f"{rep.get('masked_pixels', 0)} flipped / skip-suspect pixels zeroed "
+              f"on both sides ALL rows (incl. the {rep['explained_rows']} explained ones) <= "
               + (f"{max(v['rel'] for v in gm.values()):.2e} (tensor) / {max(v['row_rel'] for v in gm.values()):.2e} (row)"
                  if gm else "n/a (no flips)"))
     return rep, h, o
@@ -359,6 +362,33 @@ def test_metric_size_vs_oracle(hip_lib, oracle_mod, capsys, view):
     eight views bench.py cycles through (the oracle's OpenMP loops take a few seconds each on the GPU box's host cores)."""
     rep, h, o = full_size_case(oracle_mod, capsys, f"S3 view {view}", room_inputs(1_500_000, 1600, 1200, view, 8))
     assert rep["R"] > 4_000_000
+
+
+def test_trained_distribution_at_metric_size(hip_lib, oracle_mod, capsys):
+    """Verdict r4 item 5: every other scene of the suite is drawn i.i.d.  bench.py's workload `s3t` -- the 1.5 M-surfel
+    room RE-LEARNT from its own renders through the product's training path with the reference's densify / prune / SH /
+    opacity-reset schedule (g4splat_amd/trained_scene.py: clones that drifted, split children, a bimodal opacity
+    histogram, deep translucent tiles) -- at the metric resolution, one view, against the oracle with the full gate;
+    and how many of its tiles the backward hands to the four-wave kernel."""
+    from g4splat_amd import synthetic, trained_scene
+    W, H = 1600, 1200
+    scene, info = trained_scene.scene_trained(seed=0, iters=1000, P=1_500_000, width=W, height=H)
+    assert 700_000 < info["P"] < 2_200_000 and len(info["surfels_after_each_densification"]) >= 5
+    cam = synthetic.room_cameras(8, W, H, fovx_deg=90.0)[_DEFAULT_VIEWS[0]]
+    inp = dict(bg=np.array((0.3, 0.1, 0.2), np.float32), means3D=scene.means3D, colors=EMPTY, opacity=scene.opacities,
+               scales=scene.scales, rotations=scene.rotations, scale_modifier=1.0, transMat=EMPTY,
+               view=cam.world_view_transform, proj=cam.full_proj_transform, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+               H=H, W=W, sh=scene.shs, D=3, campos=cam.camera_center)
+    rep, h, o = full_size_case(oracle_mod, capsys, f"S3t view {_DEFAULT_VIEWS[0]}", inp)
+    st = hip_state(h, inp)
+    n = (st["ranges"][:, 1] - st["ranges"][:, 0]).astype(np.int64)
+    vis = h["radii"] > 0
+    aff = (st["rec_u32"][:, 3] >> 31).astype(bool) & vis
+    with capsys.disabled():
+        print(f"S3t: {info}; visible {int(vis.sum())}, REC_AFFINE {aff.sum() / max(1, (st['tiles_touched'] > 0).sum()):.3f} of the "
+              f"binned splats; tile lists: mean {n.mean():.0f}, longest {n.max()}; tiles taken by blend_bwd_hot_kernel: "
+              f"{st['hot_count']} of {len(n)}")
+    assert rep["R"] > 1_000_000
 
 
 @pytest.mark.parametrize("view,D", [(0, 3), (1, 3), (2, 0), (3, 3), (4, 3)])
@@ -430,19 +460,14 @@ def test_ten_million_gaussians_most_of_them_out_of_sight(hip_lib):
         assert not g[pad].any(), n
 
 
-@pytest.mark.parametrize("backward", ["policy", "one-wave"])
 @pytest.mark.parametrize("block", range(20))
-def test_fuzz_small_scenes(hip_lib, oracle_mod, block, backward):
+def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
     """Two hundred seeded random configurations (image sizes that are not multiples of the tile, 1-pixel-high images,
     huge and tiny splats, translucent and opaque, every SH degree, scale modifiers, backgrounds, fields of view)
     against the oracle: outputs, radii, instance counts, culled tile lists, gradients.  Frames this small take the
-    four-wave backward under the default policy; "one-wave" forces the one-wave-per-tile kernel on the same cases."""
+    four-wave backward under the default policy; every other case is run a second time with the one-wave-per-tile kernel
+    forced (the oracle's result is shared)."""
     from g4splat_amd import _lib
-    with _lib.option("bwd_hot_threshold", (1 << 30) if backward == "one-wave" else _lib.OPTION_UNSET):
-        _fuzz_block(oracle_mod, block)
-
-
-def _fuzz_block(oracle_mod, block):
     for case in range(10):
         seed = 1000 + 10 * block + case
         rng = np.random.default_rng(seed)
@@ -456,11 +481,13 @@ def _fuzz_block(oracle_mod, block):
                            scale_modifier=float(rng.choice([1.0, 1.0, 0.7, 1.6])), fov_deg=float(rng.uniform(25, 110)))
         g = cotangents(H, W, seed=seed)
         o = run_oracle(oracle_mod, inp, g)
-        h = run_hip(inp, g)
-        tag = f"seed {seed}: P={P} {W}x{H} D={D}"
-        assert_parity(h, o, inp, oracle_mod, tag=tag)
-        if o["R"] > 0:
-            check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
+        for backward in (("policy", "one-wave") if case % 2 == 0 else ("policy",)):
+            with _lib.option("bwd_hot_threshold", (1 << 30) if backward == "one-wave" else _lib.OPTION_UNSET):
+                h = run_hip(inp, g)
+                tag = f"seed {seed}: P={P} {W}x{H} D={D} ({backward})"
+                assert_parity(h, o, inp, oracle_mod, tag=tag)
+            if o["R"] > 0 and backward == "policy":
+                check_lists_against_oracle(hip_state(h, inp), o["oracle"], oracle_mod)
 
 
 def _shortcut_scene(seed):

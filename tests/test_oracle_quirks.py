@@ -205,3 +205,16 @@ def test_skip_suspects_are_the_pixels_of_the_skip_margin_map():
         for p, g in list(zip(pix, gid))[:200]:
             t = (p // 96 // 16) * 6 + (p % 96) // 16
             assert g in plist[rng[t, 0]:rng[t, 1]]
+
+
+def test_skip_suspects_margins_equal_pixel_margins():
+    """The parity gate takes its threshold margins from skip_suspects' walk (one pass over the frame for both): they must
+    be oracle.pixel_margins', bit for bit."""
+    import numpy as np
+    from common import run_oracle, scene_inputs
+    from oracle import oracle as om
+
+    inp = scene_inputs(P=3000, W=96, H=64, seed=22, D=1, scale_mul=2.0)
+    orc = run_oracle(om, inp)["oracle"]
+    _pix, _gid, m = om.skip_suspects(orc, 1e-3, with_margins=True)
+    np.testing.assert_array_equal(m, om.pixel_margins(orc))
