@@ -43,21 +43,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {
-    # name: (P, W, H, SH degree, #views)
-    "s3": (1_500_000, 1600, 1200, 3, 8),   # ScanNet++-like, BASELINE configs[2] (metric resolution)
-    "s2": (300_000, 1200, 680, 3, 8),      # Replica-room0-like, configs[1]/[3]
-    "s1": (10_000, 256, 256, 3, 1),        # configs[0]
-    "s5": (3_000_000, 1200, 680, 3, 8),    # DeepBlending-like, configs[4]
-    # S3 with a TRAINED distribution (verdict r4 item 5): the room re-learnt from its own renders through the product's
-    # training path for 1 000 iterations of the reference's densify / prune / SH / opacity-reset schedule
-    # (g4splat_amd/trained_scene.py); the surfel count is what the training leaves (about 1.5 M)
-    "s3t": (1_500_000, 1600, 1200, 3, 8),
-}
+from g4splat_amd.benchlib import (HBM_PEAK_GBS, SIMDS, STRONG_VIEWS, WORKLOADS, algorithmic_bytes, assemble_line,  # noqa: E402,F401
+                                   exchange_report, pick_headline, roofline_report, summarize_steps)
+from g4splat_amd import benchlib  # noqa: E402
+
 TRAINED_INFO = {}      # workload -> what trained_scene.scene_trained reported (printed under config.trained_scene)
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-SIMDS = 1024           # 256 CUs x 4 SIMDs
-STRONG_VIEWS = 8       # C4 = 8 training views per optimiser step over 1/2/4/8 GPUs
 
 
 def parse_args(argv=None):
@@ -126,37 +116,6 @@ def build_scene(name, device):
     dcams = [dict(view=t(c.world_view_transform), proj=t(c.full_proj_transform), campos=t(c.camera_center),
                   tanfovx=c.tanfovx, tanfovy=c.tanfovy) for c in cams]
     return scene, cams, dev, dcams, (P, W, H, D)
-
-
-def algorithmic_bytes(kernel, P, V, R, N, K, M, tiles, tile_bits):
-    """SURVEY.md 8(d) per-kernel algorithmic bytes of one forward+backward."""
-    p_s = (32 + tile_bits + 7) // 8  # SURVEY.md 8(d): the reference sorts 64-bit (tile | depth) keys over 32 + bit bits
-    return {
-        "preprocess_fwd": P * (44 + 4 + 4 + 8) + V * (12 * K + 76),
-        "blend_fwd": R * 76 + N * 60,
-        "blend_bwd": R * 76 + N * 60 + V * 72,
-        "preprocess_bwd": V * (44 + 12 * K + 72 + 36 + 3) + P * (12 + 12 + 8 + 16 + 4) + P * 12 * M + V * 12 * K,
-        "tile_sort": R * 24 * p_s,
-        "emit": R * 12,
-        "tile_ranges": R * 8 + tiles * 8,
-    }.get(kernel)
-
-
-def summarize_steps(per_step_ms, mean_ms):
-    """median / mean / max of one timed pass and whether something other than the work itself landed in it."""
-    med = statistics.median(per_step_ms)
-    disturbed = mean_ms > 1.1 * med
-    return {"median_ms": med, "mean_ms": mean_ms, "max_ms": max(per_step_ms), "min_ms": min(per_step_ms),
-            "disturbed": bool(disturbed),
-            # the steps that carry the excess: more than 1.5x the median
-            "disturbed_steps": [i for i, t in enumerate(per_step_ms) if t > 1.5 * med] if disturbed else []}
-
-
-def pick_headline(attempts):
-    """The pass the line reports: the median (by mean step time) of the undisturbed passes -- of all passes if none was
-    clean, in which case the chosen pass itself says `disturbed`."""
-    clean = [a for a in attempts if not a["disturbed"]] or attempts
-    return sorted(clean, key=lambda a: a["mean_ms"])[(len(clean) - 1) // 2]
 
 
 def main():
@@ -257,9 +216,7 @@ def main():
 
     def views_of_step(i):
         """The camera indices THIS rank renders in step i."""
-        if strong:  # shard_views: rank r renders views r, r + N, ... of the step's 8
-            return [(rank + j * world) % len(dcams) for j in range(views_per_rank)]
-        return [(rank + i * world) % len(dcams)]
+        return benchlib.views_of_step(i, rank, world, len(dcams), strong, views_per_rank)
 
     def exchange_step(radii):
         """weak scaling: the collectives (the owner exchange's begin() has been issued right after the forward; the view's
@@ -631,29 +588,9 @@ def main():
             rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:
             rccl_version = None
-        exchange_info = {
-            "backend": backend, "rccl_version": rccl_version,
-            "rccl_ranks": dist.get_world_size(),  # from the communicator, not from the command line
-            "ran": ("owner-reduce: MAX all-reduce [P + N^2] int32 + uneven all_to_all of visible rows + grouped in-place "
-                    "all_gather of the reduced shards" if exchange == "owner" else
-                    "visible-rows all-reduce: MAX all-reduce of the radii + one SUM all-reduce of the union's rows"),
-            "why": exchange_why,
-            "coalesced_gather": bool(getattr(reducer, "_coalesce", False)) if exchange == "owner" else None,
-            # dense: every owner's whole shard; sparse: only the rows some rank saw (a minority of the scene on few ranks)
-            "gather": getattr(reducer, "last_gather", None) if exchange == "owner" else None,
-            "ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None,
-            "ms_pieces": exchange_pieces,
-            "pieces_note": ("HIP-event pairs on rank 0 in the instrumented pass; begin_local + max_all_reduce are issued "
-                            "right after the forward and overlap the backward, `ms_per_step` covers what follows the "
-                            "backward (statistics, pack, all_to_all, accumulate, all_gather)"),
-            "bytes_per_rank": dict(getattr(reducer, "last_bytes", {})) or None,
-            "rows_sent_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows else None),
-            "buffer_allocations": getattr(reducer, "allocations", None),
-            # persistent buffers: nothing of the exchange is (re)allocated once the warm-up is over
-            "buffer_allocations_after_warmup": (getattr(reducer, "allocations") - exchange_allocs0
-                                                if exchange_allocs0 is not None else None),
-            "replicas_identical": replicas_identical,
-        }
+        exchange_info = exchange_report(backend, rccl_version, dist.get_world_size(), exchange, exchange_why, reducer,
+                                        exchange_ms, exchange_pieces, exchanged_rows, args.steps, exchange_allocs0,
+                                        replicas_identical)
 
     if rank != 0:
         if dist is not None:
@@ -671,95 +608,17 @@ def main():
         lib.g4s_profile_reset()
 
     step_ms = head["mean_ms"]
-    # roofline of the dominant kernel (rank 0's view mix)
+    # roofline of the dominant kernel (rank 0's view mix): SURVEY.md 8(d) bytes of one launch / its HIP-event duration,
+    # measured in this run, against the HBM peak; the blend kernels are NOT bound by HBM but by VALU issue, and `valu`
+    # says so with numbers -- wave-level VALU instructions per launch come from the committed rocprofv3 PMC passes (they
+    # cannot be read in-process; the file carries the build id of the library it was collected on and
+    # `traffic_matches_build` says whether that is the library timed here), the duration is this run's
     roofline = None
     if kernels_ms:
-        dom = max((k for k in kernels_ms if algorithmic_bytes(k, 1, 1, 1, 1, 1, 1, 1, 8) is not None),
-                  key=lambda k: kernels_ms[k])
-        tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        tile_bits = max(1, math.ceil(math.log2(tiles + 1)))
         vlist = [c for i in range(args.steps) for c in views_of_step(i)]
         Vm = sum(Vs[c] for c in vlist) / len(vlist)
         Rm = sum(Rs[c] for c in vlist) / len(vlist)
-        K = (D + 1) ** 2
-        B = algorithmic_bytes(dom, P, Vm, Rm, N, K, 16, tiles, tile_bits)
-        achieved = B / (kernels_ms[dom] * 1e-3) / 1e9
-        # What binds the kernel.  `achieved` / `peak` / `frac` are the contract's HBM figures (SURVEY.md 8(d) bytes of
-        # one launch / its HIP-event duration, measured in this run).  The blend kernels are NOT bound by HBM but by
-        # VALU issue: `valu` says so with numbers -- wave-level VALU instructions per launch come from the committed
-        # rocprofv3 PMC passes (they cannot be read in-process; the file carries the build id of the library it was
-        # collected on and `traffic_matches_build` says whether that is the library timed here), the duration is this run's.
-        pmc = pmc_profile(args.workload)
-        pk = (pmc or {}).get("kernels", {}).get(dom)
-        valu = None
-        if pk and "SQ_INSTS_VALU" in pk:
-            insts = float(pk["SQ_INSTS_VALU"])
-            t = kernels_ms[dom] * 1e-3
-            # Calibration (tools/micro/exec_rows.hip, profiles/r04_exec_lane_threshold.txt; long kernels -- round 3's "4 cycles"
-            # carried ~86 us of per-launch start-up): at 4 waves per SIMD independent v_fma_f32 issue at 2.77 nominal cycles
-            # per wave instruction (2.0 = the part's 157 TFLOP/s), a transcendental costs ~13.5, and ONE wave issues a
-            # DEPENDENT instruction every ~21 cycles -- four waves of dependent code reach 5.3 cycles per instruction.
-            # `cycles_per_instruction_profiled` is the launch's own quotient -- SIMD cycles (GRBM_GUI_ACTIVE / 8 XCDs x 1024
-            # SIMDs) / counted VALU instructions -- so nothing is assumed about the clock.  The blend kernels sit between the
-            # two: bound by how fast four (seven) waves of mostly dependent code can issue, scalar instructions and branches
-            # included, not by the FMA rate.
-            cpi = (pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS / insts) if pk.get("GRBM_GUI_ACTIVE") else None
-            FMA_CPI, DEP_CPI_4WAVES = 2.77, 5.3
-            issue = round(min(1.0, FMA_CPI / cpi), 4) if cpi else None
-            # how much of that issue rate does arithmetic on live pixels: lanes with a blending pixel / 64 per visit of the
-            # entry loop (profiles/r04_lane_util_model.txt, the oracle's exact `act` predicate on real S3 frames)
-            lane = (pmc or {}).get("useful_lane_frac", {}).get(dom)
-            valu = {"wave_instructions_per_launch": int(insts),
-                    "cycles_per_instruction_profiled": round(cpi, 3) if cpi else None,
-                    "full_rate_cycles_per_instruction": FMA_CPI,
-                    "dependent_code_cycles_per_instruction_at_4_waves": DEP_CPI_4WAVES,
-                    # share of the SIMDs' FMA issue rate the launch used, clock-free
-                    "simd_issue_utilisation": issue,
-                    "frac_of_scalar_issue": issue,
-                    "useful_lane_frac": lane,
-                    # issue share x useful lanes x (2.0 / 2.77: what independent FMAs reach of the 157 TFLOP/s): an upper
-                    # bound of the FP32 peak fraction (it counts every instruction as an FMA)
-                    "frac_of_fp32_peak": (round(issue * lane * 2.0 / FMA_CPI, 4) if (issue is not None and lane is not None) else None),
-                    "ns_per_instruction_this_run": round(t * SIMDS / insts * 1e9, 4),
-                    "calibration": "tools/micro/exec_rows.hip on MI355X (profiles/r04_exec_lane_threshold.txt): independent "
-                                   "v_fma_f32 2.77 cycles per wave instruction at 4 waves per SIMD, the blend mix (6 fma + exp + "
-                                   "rcp) 5.46, one dependent chain per wave 5.3"}
-        if valu and valu["simd_issue_utilisation"] is not None:
-            # the roof the kernel is closer to -- or neither: a small frame (S1: one wave per SIMD) runs at a third of
-            # the issue rate and 2 % of the HBM peak; that is latency, not a roofline
-            # "valu" = instruction issue / latency of the waves' own code (see `valu`), as opposed to memory
-            bound = "valu" if valu["simd_issue_utilisation"] > achieved / HBM_PEAK_GBS else "hbm"
-            if max(valu["simd_issue_utilisation"], achieved / HBM_PEAK_GBS) < 0.5:
-                bound = "latency"
-        else:
-            bound = "unknown"  # no counters for this workload / kernel: the HBM fraction below is all this run can say
-        hbm = lambda q: int((2.0 * q["FETCH_SIZE"] + q["WRITE_SIZE"]) * 1024) if q and "FETCH_SIZE" in q and "WRITE_SIZE" in q else None
-        traffic = hbm(pk)
-        # whole step against the HBM roofline: every kernel's 8(d) bytes / the step time of this run, and next to it the
-        # bytes the kernels of THIS build actually moved (sum of the PMC tables: this build's 2-pass tile partition moves
-        # far less than the 6-pass 64-bit sort the 8(d) table prices)
-        B_step = (P * 60 + Vm * (12 * K + 76) + Rm * 12 + Rm * 24 * ((32 + tile_bits + 7) // 8) + Rm * 8 + tiles * 8
-                  + 2 * (Rm * 76 + N * 60) + Vm * 72 + Vm * (44 + 12 * K + 72 + 36 + 3) + P * 52 + P * 12 * 16 + Vm * 12 * K)
-        moved = [hbm(q) for q in (pmc or {}).get("kernels", {}).values()]
-        moved = sum(m for m in moved if m) if moved and all(m is not None for m in moved) else None
-        pmc_build = (pmc or {}).get("build_id")
-        roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": (pmc or {}).get("provenance"),
-                    "traffic_build_id": pmc_build, "traffic_matches_build": (pmc_build == build_id) if pmc else None,
-                    "algorithmic_bytes_per_launch": int(B), "avg_launch_ms": round(kernels_ms[dom], 4),
-                    "valu": valu,
-                    "whole_step": {"algorithmic_bytes": int(B_step), "GBps": round(B_step / (step_ms * 1e-3) / 1e9, 1),
-                                   "frac_of_hbm_peak": round(B_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "moved_bytes": moved,
-                                   "moved_frac_of_hbm_peak": (round(moved / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                                              if moved else None),
-                                   "note": "algorithmic_bytes: SURVEY.md 8(d) bytes of all kernels, priced as the table prices "
-                                           "them (the reference's 64-bit (tile | depth) key sort, p_s = ceil((32 + bit) / 8) "
-                                           "passes over all instances) / this run's step time; moved_bytes: HBM bytes the "
-                                           "kernels of this build moved per step (PMC, the kernels in the traffic table). "
-                                           "north_star's 40 % of the HBM peak is not reachable while the two blend kernels "
-                                           "-- three quarters of the step -- are VALU-issue-bound"}}
+        roofline = roofline_report(kernels_ms, pmc_profile(args.workload), build_id, P, Vm, Rm, W, H, D, step_ms)
 
     vif = None
     if world == 1 and not strong and args.views_in_flight > 1 and len(dcams) > 1:
@@ -789,67 +648,14 @@ def main():
                 others[wl] = b
             cpu_baseline["other_workloads"] = others
 
-    kernels_sum = sum(kernels_ms.values()) if kernels_ms else None
-    out = {
-        "metric": "rasterized Gaussians/s fwd+bwd @1600x1200" if args.workload == "s3"
-        else f"rasterized Gaussians/s fwd+bwd @{W}x{H}",
-        # value = units of the K steps / the time of the K steps (barrier + synchronize on both sides, MAX over ranks) of
-        # the median pass (see `timing`)
-        "value": units / (args.steps * step_ms * 1e-3), "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": args.scaling,
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {P} surfels (room box" + (", re-learnt: trained distribution" if args.workload in TRAINED_INFO else "")
-                               + f"), {W}x{H}, SH degree {D}, {len(dcams)} views, "
-                               + (f"{STRONG_VIEWS} views per step over {world} GPU(s): {views_per_rank} per GPU, accumulated "
-                                  f"locally ({min(3, views_per_rank)} in flight)" if strong else "1 view/GPU/step"),
-                   "P": P, "width": W, "height": H,
-                   "trained_scene": TRAINED_INFO.get(args.workload),
-                   "sh_degree": D, "visible_per_view": round(units / args.steps / world / views_per_rank),
-                   "instances_per_view": round(inst / args.steps / world / views_per_rank),
-                   "views_per_step": world * views_per_rank,
-                   "visible_by_view_rank0": {str(c): Vs[c] for c in sorted(Vs)},
-                   "forward": "presized (no host read-back)" if (args.presized or strong) else "reference-shaped",
-                   "parallelism": f"view-dp{world}" + ((("+rccl" if backend == "nccl" else "+" + backend) +
-                                                        ("-owner-reduce(all_to_all+all_gather)" if exchange == "owner"
-                                                         else "-visible-rows-" + exchange)) if world > 1 else ""),
-                   "exchanged_rows_per_step": (round(sum(exchanged_rows[-args.steps:]) / args.steps) if exchanged_rows
-                                               else None),
-                   # GPU time of the gradient exchange per step on rank 0 (what follows the backward), from the
-                   # instrumented pass; it is part of every timed step at N > 1
-                   "exchange_ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None},
-        "build_id": build_id,
-        "timing": {"protocol": "passes of exactly K steps between barrier + synchronize (host clock, MAX over ranks), one HIP "
-                               "event behind every step; repeated until 3 passes are undisturbed (mean <= 1.1 x median step); "
-                               "ms_per_step = mean step time of the MEDIAN undisturbed pass; `median_ms` = SURVEY.md 8(d)'s "
-                               "median step of that pass (the steps cycle through views of different cost, so the median "
-                               "of the mix sits ~2 % above its mean)",
-                   "passes": len(attempts), "undisturbed_passes": sum(1 for a in attempts if not a["disturbed"]),
-                   "mean_ms": round(head["mean_ms"], 4), "median_ms": round(head["median_ms"], 4),
-                   "max_ms": round(head["max_ms"], 4), "min_ms": round(head["min_ms"], 4),
-                   "per_step_ms": head["per_step_ms"],
-                   "value_from_median_step": units / (args.steps * head["median_ms"] * 1e-3),
-                   "disturbed": head["disturbed"], "disturbed_steps": head["disturbed_steps"],
-                   "attempts": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
-                                 if k != "per_step_ms" or a["disturbed"]} for a in attempts],
-                   "warmup_extra_steps": settle["extra_steps"], "warmup_settled": settle["settled"],
-                   "warmup_windows_ms_per_step": settle["windows_ms_per_step"],
-                   "device_allocations_in_timed_region": int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)),
-                   "vs_sustained": (round(step_ms / sustained["ms_per_step"], 4) if sustained else None),
-                   "vs_kernels_sum": (round(step_ms / kernels_sum, 4) if (kernels_sum and not strong and world == 1) else None)},
-        "gaussians_total_per_s": P * args.steps * world * views_per_rank / (args.steps * step_ms * 1e-3),
-        "instances_per_s": inst / (args.steps * step_ms * 1e-3),
-        "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},
-        # per-kernel durations come from a second pass over the same K steps with a HIP-event pair around every kernel
-        # group on the launch stream; the events cost GPU time themselves, so that pass is not the headline
-        "kernel_timing": ({"pass": "same steps repeated with HIP events around each kernel group",
-                           "ms_per_step_with_events": round(elapsed_events / args.steps * 1e3, 4),
-                           "clock_state": ("settled (behind the sustained pass)" if sustained else "as found")}
-                          if elapsed_events is not None else None),
-        "sustained": sustained,
-        "exchange": exchange_info,
-        "views_in_flight": vif,
-        "roofline": roofline, "cpu_baseline": cpu_baseline,
-    }
+    out = assemble_line(dict(
+        workload=args.workload, P=P, W=W, H=H, D=D, n_views=len(dcams), world=world, views_per_rank=views_per_rank,
+        strong=strong, steps=args.steps, warmup=args.warmup, scaling=args.scaling, backend=backend, exchange=exchange,
+        presized=args.presized, units=units, inst=inst, Vs=Vs, attempts=attempts, head=head, settle=settle,
+        device_allocations=int(mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0)), kernels_ms=kernels_ms,
+        elapsed_events_s=elapsed_events, sustained=sustained, exchange_info=exchange_info, exchanged_rows=exchanged_rows,
+        exchange_ms=exchange_ms, views_in_flight=vif, roofline=roofline, cpu_baseline=cpu_baseline, build_id=build_id,
+        trained_scene=TRAINED_INFO.get(args.workload)))
     print(json.dumps(out))
     sys.stdout.flush()
     if dist is not None:
