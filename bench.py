@@ -209,6 +209,9 @@ def main():
         reducer = OwnerReduce(row_views) if exchange == "owner" else RowSparseAllReduce(bucket, row_views)
     exchanged_rows = []
     exchange_events = None  # list of (start, stop) events while the instrumented pass runs
+    # weak scaling: one view per exchange, so the backward can write the send rows itself (OwnerReduce.prepack);
+    # G4S_BENCH_PREPACK=0 keeps the pack launch (A/B)
+    prepack = (dist is not None and exchange == "owner" and not strong and os.environ.get("G4S_BENCH_PREPACK", "1") != "0")
 
     pstate = None
     pipe = None
@@ -227,7 +230,8 @@ def main():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         if exchange == "owner":
-            reducer.finish()  # (reducer.max_radii = MAX over the ranks of the radii, from begin()'s collective)
+            # (reducer.max_radii = MAX over the ranks of the radii, from begin()'s collective)
+            reducer.finish(prepacked=prepack)
             exchanged_rows.append(reducer.last_rows_sent)
         else:
             rmax.copy_(radii)
@@ -259,6 +263,8 @@ def main():
             # itself (g4s_rasterizer_backward_accumulate, first_view: every row written like the plain call): no torch
             # kernels between the backward and the exchange
             out = dict(grad_out, accumulate="first", view_stats=side)
+            if prepack:  # ... and so do the rows this rank sends to the owners, already in the all_to_all's layout
+                out["packed"] = reducer.prepack(radii > 0)
         _C.rasterize_gaussians_backward(bg, dev["means3D"], radii, empty, dev["scales"], dev["rotations"],
                                         1.0, empty, cam["view"], cam["proj"], cam["tanfovx"], cam["tanfovy"],
                                         dL_dcolor, dL_dothers, dev["sh"], D, cam["campos"], geom, R, binning,
@@ -389,6 +395,7 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0:
             exchange = "allreduce"
+            prepack = False
             if exchange_why in ("default", "requested"):
                 exchange_why = "owner exchange failed in warm-up on another rank"
             reducer = RowSparseAllReduce(bucket, row_views)

@@ -16,6 +16,10 @@ c_p = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 
+class G4sPackedRows(ctypes.Structure):  # g4s_packed_rows
+    _fields_ = [("rows", ctypes.c_void_p), ("block_offs", ctypes.c_void_p), ("capacity", ctypes.c_longlong)]
+
+
 class G4sLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_size_t) for n in (
         "rec", "clamped", "depth_sorted", "tiles_touched", "geom_bytes", "entries", "qhit", "binning_bytes", "ranges",
@@ -42,6 +46,9 @@ SIGNATURES = {
     "g4s_rasterizer_backward_accumulate": (c_i, [c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p,
                                                  c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                                  c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_sz, c_p, c_i, c_p]),
+    "g4s_rasterizer_backward_accumulate_packed": (c_i, [c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p,
+                                                        c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                                        c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_sz, c_p, c_i, c_p]),
     "g4s_rasterizer_forward_presized": (c_i, [c_p, c_sz, c_p, c_sz, c_p, c_sz, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p,
                                               c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_i,
                                               c_p]),

@@ -188,6 +188,8 @@ def exchange_report(backend, rccl_version, world, exchange, why, reducer, exchan
         "coalesced_gather": bool(getattr(reducer, "_coalesce", False)) if owner else None,
         # dense: every owner's whole shard; sparse: only the rows some rank saw (a minority of the scene on few ranks)
         "gather": getattr(reducer, "last_gather", None) if owner else None,
+        # True: the backward's per-Gaussian kernel wrote the send rows itself (no pack launch behind the backward)
+        "prepacked": getattr(reducer, "last_prepacked", None) if owner else None,
         "ms_per_step": round(exchange_ms, 4) if exchange_ms is not None else None,
         "ms_pieces": pieces,
         "pieces_note": ("HIP-event pairs on rank 0 in the instrumented pass; begin_local + max_all_reduce are issued "

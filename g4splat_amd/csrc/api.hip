@@ -504,7 +504,7 @@ static int rasterizer_backward_impl(
     const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
     float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh, float* dL_dsh_rest, float* dL_dscale,
     float* dL_drot, char* workspace, size_t workspace_bytes, int debug, void* stream_, bool accumulate = false,
-    void* after_event = nullptr, float* view_stats = nullptr) {
+    void* after_event = nullptr, float* view_stats = nullptr, const g4s_packed_rows* packed = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     t_err[0] = 0;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "bad sizes");
@@ -608,6 +608,13 @@ static int rasterizer_backward_impl(
     pb.shs_rest = shs_rest; pb.dL_dsh_rest = dL_dsh_rest; pb.sh_prezeroed = sh_prezeroed;
     pb.accumulate = accumulate;
     pb.view_stats = view_stats;
+    if (packed != nullptr && packed->rows != nullptr) {
+        if (accumulate) return fail(G4S_ERR_INVALID_ARGUMENT, "packed rows: only the first view of a batch (first_view != 0) can write them");
+        if (!packed->block_offs || packed->capacity < 0 || shs == nullptr)
+            return fail(G4S_ERR_INVALID_ARGUMENT, "packed rows: block_offs must not be NULL, capacity >= 0, colours from SH");
+        pb.packed_rows = packed->rows; pb.packed_block_offs = packed->block_offs;
+        pb.packed_capacity = (uint32_t)(packed->capacity < 0xFFFFFFFFll ? packed->capacity : 0xFFFFFFFFll);
+    }
     // The blend backward above touches only this call's own state; the per-Gaussian kernel below adds into tensors that
     // the previous view's backward -- on another stream -- may still be adding into: it waits for the caller's event.
     if (after_event) HIP_TRY(hipStreamWaitEvent(stream, (hipEvent_t)after_event, 0));
@@ -655,6 +662,26 @@ extern "C" int g4s_rasterizer_backward_split_sh(
 }
 
 // Gradient accumulation over views (include/g4s_rasterizer.h).  sh_rest == NULL: sh_dc is the packed [P,M,3] tensor.
+extern "C" int g4s_rasterizer_backward_accumulate_packed(
+    int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+    const float* sh_dc, const float* sh_rest, const float* scales, float scale_modifier, const float* rotations,
+    const float* transMat_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity,
+    float* dL_dcolor, float* dL_dmean3D, float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale,
+    float* dL_drot, float* view_stats, int first_view, const g4s_packed_rows* packed, char* workspace, size_t workspace_bytes,
+    void* after_event, int debug, void* stream) {
+    t_err[0] = 0;
+    if (P > 0 && (!sh_dc || M < 1 || (sh_rest && M > 1 && !dL_dsh_rest)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "accumulating backward needs SH coefficients (packed, or sh_dc + sh_rest / dL_dsh_rest)");
+    return rasterizer_backward_impl(P, D, M, R, background, width, height, means3D, sh_dc, (sh_rest && M > 1) ? sh_rest : nullptr,
+                                    nullptr, scales, scale_modifier, rotations, transMat_precomp, viewmatrix, projmatrix, campos,
+                                    tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths,
+                                    dL_dmean2D, dL_dnormal, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dtransMat, dL_dsh_dc,
+                                    (sh_rest && M > 1) ? dL_dsh_rest : nullptr, dL_dscale, dL_drot, workspace, workspace_bytes,
+                                    debug, stream, first_view == 0, after_event, view_stats, packed);
+}
+
 extern "C" int g4s_rasterizer_backward_accumulate(
     int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
     const float* sh_dc, const float* sh_rest, const float* scales, float scale_modifier, const float* rotations,

@@ -279,6 +279,13 @@ struct PreprocessBwdArgs {
     float* dL_dsh_rest;
     bool sh_prezeroed;  // dL_dsh (and dL_dsh_rest) were cleared by the blend backward: K8 writes visible rows only
     float* view_stats;  // optional [P,2]: (||dL_dmean2D.xy|| of this view, visible ? 1 : 0), written or -- accumulate -- added
+    // Optional second copy of the parameter gradients, PACKED: one row of 3 M + 13 floats per Gaussian with radii > 0, in
+    // index order -- [dL_dmean3D 3 | dL_dsh 3 M | dL_dopacity 1 | dL_dscale 2 | dL_drot 4 | view_stats 2 | bits(index)] --
+    // the send buffer of the multi-GPU owner exchange (g4s_packed_rows, include/g4s_rasterizer.h).  Row of a Gaussian =
+    // packed_block_offs[its 256-block] + the visible Gaussians before it in the block.
+    float* packed_rows;
+    const uint32_t* packed_block_offs;
+    uint32_t packed_capacity;  // rows; a row beyond it is dropped
     bool accumulate;    // parameter gradients are ADDED to their tensors (views accumulated in place); nothing is cleared
     float *dL_dmean2D, *dL_dnormal, *dL_dopacity, *dL_dcolor, *dL_dmean3D, *dL_dtransMat, *dL_dsh, *dL_dscale,
         *dL_drot;

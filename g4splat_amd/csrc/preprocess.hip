@@ -509,6 +509,39 @@ __device__ __forceinline__ F3 dnormvdv(F3 v, F3 dv) {
                (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32);
 }
 
+// The SH basis values sh_backward multiplies the colour gradient with (coef[i] = d rgb / d sh_i; zero above the active
+// degree): the same expressions in the same order, so the products are the bits sh_backward stores.
+__device__ __forceinline__ void sh_coefficients(int deg, F3 pos, F3 campos, float* coef /*16*/) {
+    const F3 d = mk3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
+    const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+    const float x = d.x / len, y = d.y / len, z = d.z / len;
+#pragma unroll
+    for (int i = 0; i < 16; i++) coef[i] = 0.0f;
+    coef[0] = SH_C0;
+    if (deg > 0) {
+        coef[1] = -SH_C1 * y;
+        coef[2] = SH_C1 * z;
+        coef[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            coef[4] = c_SH_C2[0] * xy;
+            coef[5] = c_SH_C2[1] * yz;
+            coef[6] = c_SH_C2[2] * (2.f * zz - xx - yy);
+            coef[7] = c_SH_C2[3] * xz;
+            coef[8] = c_SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                coef[9] = c_SH_C3[0] * y * (3.f * xx - yy);
+                coef[10] = c_SH_C3[1] * xy * z;
+                coef[11] = c_SH_C3[2] * y * (4.f * zz - xx - yy);
+                coef[12] = c_SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                coef[13] = c_SH_C3[4] * x * (4.f * zz - xx - yy);
+                coef[14] = c_SH_C3[5] * z * (xx - yy);
+                coef[15] = c_SH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
 // backward.cu:20-139.  Writes all M coefficients of dL_dsh (zeros above the active degree)
 // and returns the view-direction term to add to dL_dmean.
 // ACC: the coefficients are ADDED to what dsh holds (gradient accumulation over views) and nothing is cleared.
@@ -856,12 +889,30 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     __shared__ float s_buf[256 * K8_OUT_FLOATS];
     float* s_sum = s_buf;
     __shared__ uint32_t s_off[256], s_cnt[256];
-    __shared__ uint8_t s_vis[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_vis[256];  // (read back sixteen bytes at a time for the packed rows)
     const int t = (int)threadIdx.x;
     const int idx = (int)(blockIdx.x * 256 + t);
     const bool in_range = idx < a.P;
     fold_block(a, z0, z1, s_sum, s_off, s_cnt, s_vis);
     const bool visible = s_vis[t] != 0;
+    // the packed gradient row of this Gaussian, if the caller asked for them (visible Gaussians in index order)
+    // (the rows of a block are consecutive in the packed buffer: they are assembled in LDS and leave as one coalesced run)
+    uint32_t prank = 0, pcount = 0, pbase = 0;  // this Gaussian's rank among the block's visible ones, their number, the block's first row
+    if (a.packed_rows != nullptr) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {  // (s_vis is one byte per thread, 0 / 1: sixty-four bytes per wave)
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint4 v = reinterpret_cast<const uint4*>(s_vis)[4 * w + i];
+                c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+            }
+            if (w < (t >> 6)) prank += c;
+            pcount += c;
+        }
+        prank += (uint32_t)__popcll(__ballot(visible) & lanes_below_mask());
+        pbase = a.packed_block_offs[blockIdx.x];
+    }
     const float4* rq = reinterpret_cast<const float4*>(a.rec) + (size_t)(in_range ? idx : 0) * REC_QUADS;
 
     // record order (blend backward): 0..14 = colour, normal, T; 15 = opacity; 16..17 = low-pass centre terms
@@ -1031,7 +1082,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         dmean2[1] = (float)(dT_out[5] * depth_T8 * 0.5 * (float)a.H);
     }
     // (rows of dL_dsh that belong to invisible Gaussians: cleared by the fold phase above or beside the blend backward)
-
     // Outputs: every thread parks its 28 floats in LDS, then the block writes each tensor's 256-row region with
     // coalesced 16-byte stores -- 7 store instructions per thread instead of 28 strided dword stores, three quarters of
     // which only carried the zeros of invisible Gaussians.
@@ -1084,6 +1134,44 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         flush(a.dL_dscale, 2, K8_OUT_SCALE, ACC);
         flush(a.dL_drot, 4, K8_OUT_ROT, ACC);
         flush(a.view_stats, 2, K8_OUT_STATS, ACC);
+    }
+    // The packed copy of the visible Gaussians' parameter gradients (PreprocessBwdArgs::packed_rows): the block's rows are
+    // consecutive in the buffer, so they are assembled in LDS -- the SH block is formed again from the colour gradient and
+    // the direction, 48 multiplies, instead of keeping 48 registers alive across the flush above -- and leave as one
+    // coalesced run of dwords.  (Written straight from the threads, 61 dword stores at a 244-byte lane stride, the same
+    // rows cost the kernel 0.064 ms at S3; tools/micro/prepack_cost.py.)  K8_PACK_ROWS rows fit the buffer; a block with
+    // more visible Gaussians (half of its 256) writes the surplus directly.
+    if (a.packed_rows != nullptr && pcount != 0) {
+        const int RW = 3 * a.M + 13;
+        const int lds_rows = imin_((int)pcount, (256 * K8_OUT_FLOATS) / RW);
+        __syncthreads();  // the flush has read s_buf
+        if (visible && pbase + prank < a.packed_capacity) {
+            float* row = (int)prank < lds_rows ? s_buf + (size_t)prank * RW : a.packed_rows + (size_t)(pbase + prank) * RW;
+            row[0] = dmean3[0]; row[1] = dmean3[1]; row[2] = dmean3[2];
+            // dL_dsh = coef(direction) x dL_dcolor, clamped channels zeroed (sh_backward, backward.cu:20-139)
+            const F3 pos = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+            float coef[16];
+            sh_coefficients(a.D, pos, mk3(a.campos[0], a.campos[1], a.campos[2]), coef);
+            const uint32_t cb = a.clamped[idx];
+            // (times 0 / 1 like sh_backward, not a select: a clamped channel's gradient keeps the sign of its zero)
+            const float d0 = g[0] * ((cb & 1u) ? 0.0f : 1.0f), d1 = g[1] * ((cb & 2u) ? 0.0f : 1.0f), d2 = g[2] * ((cb & 4u) ? 0.0f : 1.0f);
+            for (int i = 0; i < a.M; i++) {
+                const float cf = i < 16 ? coef[i] : 0.0f;
+                row[3 + 3 * i] = cf * d0; row[3 + 3 * i + 1] = cf * d1; row[3 + 3 * i + 2] = cf * d2;
+            }
+            float* q = row + 3 + 3 * a.M;
+            q[0] = g[17];
+            q[1] = dscale[0]; q[2] = dscale[1];
+            q[3] = drot.x; q[4] = drot.y; q[5] = drot.z; q[6] = drot.w;
+            q[7] = sqrtf(dmean2[0] * dmean2[0] + dmean2[1] * dmean2[1]);  // (the view_stats columns)
+            q[8] = 1.0f;
+            q[9] = __int_as_float(idx);
+        }
+        __syncthreads();
+        const uint32_t room = a.packed_capacity > pbase ? a.packed_capacity - pbase : 0u;
+        const int n = imin_(lds_rows, (int)(room < 256u ? room : 256u)) * RW;
+        float* dst = a.packed_rows + (size_t)pbase * RW;
+        for (int i = t; i < n; i += 256) dst[i] = s_buf[i];
     }
 }
 

@@ -234,7 +234,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     batch's densification statistics (sum of the per-view ||dL_dmeans2D.xy||, number of views that saw the Gaussian),
     written by the "first" call and added to by the others.  `out["after"]`: a recorded torch.cuda.Event -- the stream
     waits for it between the blend backward and the accumulating per-Gaussian kernel (views in flight on several
-    streams: pipeline.ViewPipeline hands out the previous view's event).
+    streams: pipeline.ViewPipeline hands out the previous view's event).  `out["packed"] = (rows, block_offs)` (only with
+    accumulate = "first"; g4s_rasterizer_backward_accumulate_packed): the per-Gaussian kernel also leaves the parameter
+    gradients of the visible Gaussians PACKED, one row of 3 M + 13 floats each in index order -- [dL_dmeans3D | dL_dsh |
+    dL_dopacity | dL_dscales | dL_drotations | view_stats | bits(index)], the send buffer of parallel.OwnerReduce --
+    in `rows` (float32 [capacity, 3 M + 13]); `block_offs` = int32 / uint32 [ceil(P / 256)], the number of Gaussians with
+    radii > 0 in the 256-blocks before each block (OwnerReduce.prepack() computes both).
 
     The backward reads AND updates the forward's state chunks (the validity bytes of its gradient records live in the
     binning chunk): run at most one backward at a time per forward state, and with a PresizedState -- whose chunks
@@ -269,6 +274,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         first_view = accumulate == "first"
         accumulate = bool(accumulate)
         after = given.pop("after", None)
+        packed = given.pop("packed", None)
         view_stats = given.pop("view_stats", None)
         if view_stats is not None and not accumulate:
             raise RuntimeError("out['view_stats'] only applies to an accumulating backward (accumulate = True or 'first')")
@@ -284,6 +290,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 raise RuntimeError("out['accumulate']: colours must come from SH")
         elif after is not None:
             raise RuntimeError("out['after'] only applies to an accumulating backward")
+        if packed is not None:
+            if not first_view:
+                raise RuntimeError("out['packed'] only applies to accumulate = 'first' (the rows hold ONE view's gradients)")
+            prow, poffs = packed
+            if (prow.ndim != 2 or prow.size(1) != 3 * M + 13 or prow.dtype != torch.float32 or prow.device != dev
+                    or not prow.is_contiguous()):
+                raise RuntimeError(f"out['packed'][0] must be a contiguous float32 (capacity, {3 * M + 13}) tensor on {dev}")
+            if (poffs.numel() != (P + 255) // 256 or poffs.dtype not in (torch.int32, torch.uint32) or poffs.device != dev
+                    or not poffs.is_contiguous()):
+                raise RuntimeError(f"out['packed'][1] must be a contiguous int32 ({(P + 255) // 256},) tensor on {dev}")
 
         def make(shape, name=None, align=4, **kw):
             t = given.pop(name, None)
@@ -336,13 +352,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 dc, rest = (_f32c(sh_dc), _f32c(sh_rest)) if split else (_f32c(sh, 16), None)
                 gdc, grest = (dL_dsh[0], dL_dsh[1]) if split else (dL_dsh, None)
                 ev = ctypes.c_void_p(after.cuda_event if after is not None else 0)
-                rc = lib.g4s_rasterizer_backward_accumulate(
+                pk = None
+                if packed is not None:
+                    pk = _lib.G4sPackedRows(packed[0].data_ptr(), packed[1].data_ptr(), int(packed[0].size(0)))
+                rc = lib.g4s_rasterizer_backward_accumulate_packed(
                     P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(m3), _ptr(dc), _ptr(rest), _ptr(sc),
                     float(scale_modifier), _ptr(rot), _ptr(tm), _ptr(vm), _ptr(pm), _ptr(cp), float(tan_fovx),
                     float(tan_fovy), _ptr(rad), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(gc),
                     _ptr(go), _ptr(dL_dmeans2D), _ptr(dL_dnormal), _ptr(dL_dopacity), _ptr(dL_dcolors),
                     _ptr(dL_dmeans3D), _ptr(dL_dtransMat), _ptr(gdc), _ptr(grest), _ptr(dL_dscales),
-                    _ptr(dL_drotations), _ptr(view_stats), int(first_view), _ptr(workspace), ws_bytes, ev,
+                    _ptr(dL_drotations), _ptr(view_stats), int(first_view),
+                    ctypes.byref(pk) if pk is not None else None, _ptr(workspace), ws_bytes, ev,
                     int(bool(debug)), stream)
             elif split:
                 dc, rest = _f32c(sh_dc), _f32c(sh_rest)

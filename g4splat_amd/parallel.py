@@ -277,6 +277,30 @@ class OwnerReduce:
             self.allocations += 1
         return buf
 
+    def prepack(self, visible: torch.Tensor):
+        """-> (rows, block_offs) for `_C.rasterize_gaussians_backward(..., out={"accumulate": "first", "packed": ...})`: the
+        per-Gaussian kernel of the backward then writes this rank's visible rows straight into the exchange's send layout
+        (row-major, index column last) and `finish(prepacked=True)` sends from there -- the pack launch between the backward
+        and the all_to_all (0.08 ms at 1.5 M surfels) is gone.  Preconditions: ONE view per exchange on this rank (the rows
+        hold that view's gradients), `visible` is exactly `radii > 0` of that view, and the row tensors are, in this order,
+        dL_dmeans3D [P,3], dL_dsh [P,M,3] as [P,3M], dL_dopacity [P,1], dL_dscales [P,2], dL_drotations [P,4] and the
+        view_stats [P,2] the same backward writes.  `rows` holds P rows (a persistent buffer; P x (3 M + 14) x 4 bytes)."""
+        if self.widths[0] != 3 or self.widths[2:] != [1, 2, 4, 2] or self.widths[1] % 3:
+            raise RuntimeError("OwnerReduce.prepack(): the row tensors must be means3D 3 | sh 3M | opacity 1 | scales 2 | "
+                               f"rotations 4 | view_stats 2, got widths {self.widths}")
+        if getattr(self, "_packed_all", None) is None:
+            with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
+                self._packed_all = torch.empty(self.P, self.width + 1, device=self.dev)
+                self._pad256 = torch.zeros((self.P + 255) // 256 * 256, dtype=torch.int32, device=self.dev)
+                self._block_offs = torch.zeros((self.P + 255) // 256, dtype=torch.int32, device=self.dev)
+            self.allocations += 1
+        # visible Gaussians in the 256-blocks before each block (three small launches beside the backward)
+        self._pad256[:self.P].copy_(visible)
+        counts = self._pad256.view(-1, 256).sum(dim=1, dtype=torch.int32)
+        torch.cumsum(counts, dim=0, out=self._block_offs)
+        self._block_offs.sub_(counts)
+        return self._packed_all, self._block_offs
+
     # ---- first half: sizes, overlapped with the backward -----------------------------------------------------------
     def begin(self, visible: torch.Tensor, radii: Optional[torch.Tensor] = None):
         """`visible`: bool[P], the rows this rank's views can have touched (radii > 0, OR-ed over its views);
@@ -388,9 +412,10 @@ class OwnerReduce:
             issue()
 
     # ---- second half: rows to their owners, owners accumulate, (optionally) everybody gets every shard ------------
-    def finish(self, gather: bool = True):
+    def finish(self, gather: bool = True, prepacked: bool = False):
         """Reduces the rows in place.  gather=True: on return every row view holds the sum over all ranks.
         gather=False: only this rank's own rows [bounds()) do (what an owner-applied optimiser needs).
+        prepacked=True: the backward has already written this rank's visible rows into prepack()'s buffer.
 
         PRECONDITION: a row this rank did not flag `visible` in begin() holds zeros here (what the rasterizer's backward
         leaves: every gradient of a Gaussian with radii == 0 is zero).  Only visible rows travel to their owners, and the
@@ -401,6 +426,7 @@ class OwnerReduce:
         if not self._pending:
             raise RuntimeError("OwnerReduce.finish() without begin()")
         self._pending = False
+        self.last_prepacked = bool(prepacked)
         if getattr(self, "debug_checks", False):
             hidden = ~self._visible_last
             bad = sum(int((r[hidden] != 0).any().item()) for r in self.rows)
@@ -423,34 +449,48 @@ class OwnerReduce:
         n, m = sum(send), sum(recv)
         W = self.width
         with (torch.cuda.device(self.dev) if self.hip else _nullctx()):
-            out_rows = self._buffer("_send", n)[:n]
-            in_rows = self._buffer("_recv", m)[:m]
-            # pack my visible rows, [n, width + 1] row-major: the rows for owner d are one contiguous range, and the
-            # last column carries the row index (int32 bits), so rows and indices travel in ONE all_to_all
-            if self.hip:
-                with self._timed("pack"):
-                    if a:
-                        self._rows_kernel(self._idx[:a], a, out_rows[:a], 10)
-                    if total - b:
-                        self._rows_kernel(self._idx[b:total], total - b, out_rows[a:], 10)
+            if prepacked:
+                # the backward's per-Gaussian kernel has written ALL of this rank's visible rows, in index order, into
+                # prepack()'s buffer: the rows for owner d are the range [sum(counts[:d]), + counts[d]) of it.  My own rows
+                # sit in the middle; all_to_all_single wants consecutive pieces, so they take part as a piece to myself (a
+                # device-local copy of 1 / world of the rows inside the collective) and are skipped below -- my
+                # contribution already sits in my slice of the row tensors.
+                if getattr(self, "_packed_all", None) is None:
+                    raise RuntimeError("OwnerReduce.finish(prepacked=True) without prepack()")
+                send[self.rank] = recv[self.rank] = b - a
+                m = sum(recv)
+                in_rows = self._buffer("_recv", m)[:m]
+                with self._timed("all_to_all"):
+                    dist.all_to_all_single(in_rows, self._packed_all[:total], recv, send, group=self.group)
             else:
-                idx = torch.cat((self._idx[:a], self._idx[b:total]))
-                off = 0
-                for r, w in zip(self.rows, self.widths):
-                    out_rows[:, off:off + w] = r.index_select(0, idx)
-                    off += w
-                out_rows[:, W] = idx.to(torch.int32).view(torch.float32)
-            with self._timed("all_to_all"):
-                dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
-            self.last_bytes["all_to_all_sent"] = n * (W + 1) * 4
-            self.last_bytes["all_to_all_received"] = m * (W + 1) * 4
+                in_rows = self._buffer("_recv", m)[:m]
+                out_rows = self._buffer("_send", n)[:n]
+                # pack my visible rows, [n, width + 1] row-major: the rows for owner d are one contiguous range, and the
+                # last column carries the row index (int32 bits), so rows and indices travel in ONE all_to_all
+                if self.hip:
+                    with self._timed("pack"):
+                        if a:
+                            self._rows_kernel(self._idx[:a], a, out_rows[:a], 10)
+                        if total - b:
+                            self._rows_kernel(self._idx[b:total], total - b, out_rows[a:], 10)
+                else:
+                    idx = torch.cat((self._idx[:a], self._idx[b:total]))
+                    off = 0
+                    for r, w in zip(self.rows, self.widths):
+                        out_rows[:, off:off + w] = r.index_select(0, idx)
+                        off += w
+                    out_rows[:, W] = idx.to(torch.int32).view(torch.float32)
+                with self._timed("all_to_all"):
+                    dist.all_to_all_single(in_rows, out_rows, recv, send, group=self.group)
+            self.last_bytes["all_to_all_sent"] = n * (W + 1) * 4          # (through the links: my own piece excluded)
+            self.last_bytes["all_to_all_received"] = (m - recv[self.rank]) * (W + 1) * 4
             # owner: my own contribution already sits in my slice; add the other ranks' rows to it, source by source (a
             # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
             o = 0
             with self._timed("accumulate"):
                 for s_ in range(self.world):
                     c = recv[s_]
-                    if c:
+                    if c and s_ != self.rank:  # (prepacked: my own rows came back to me; they are already in place)
                         if self.hip:
                             self._rows_kernel(None, c, in_rows[o:o + c], 15)
                         else:

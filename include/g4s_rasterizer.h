@@ -190,6 +190,41 @@ int g4s_rasterizer_backward_accumulate(
     char* workspace, size_t workspace_bytes, void* after_event, int debug, void* stream);
 
 /*
+ * g4s_rasterizer_backward_accumulate that ALSO leaves the parameter gradients of the view PACKED (extension, for the
+ * multi-GPU owner exchange of SURVEY.md 8(e): the rows a rank sends to the owners of its visible Gaussians).  The
+ * per-Gaussian kernel writes, next to the tensors, one row per Gaussian with radii > 0, in index order:
+ *     [dL_dmean3D 3 | dL_dsh 3 M (all coefficients, dc first) | dL_dopacity 1 | dL_dscale 2 | dL_drot 4 |
+ *      view_stats 2 (||dL_dmean2D.xy||, 1) | bits(Gaussian index) 1]  =  3 M + 13 floats
+ * -- the buffer layout of g4s_pack_rows(mode bits 1 | 3) over those tensors, so that the exchange no longer needs its pack
+ * launch (0.08 ms at 1.5 M surfels, on the critical path between the backward and the all_to_all).
+ *   packed->rows        [capacity, 3 M + 13] floats; rows beyond `capacity` are dropped (the caller compares the count it
+ *                       knows with its capacity)
+ *   packed->block_offs  DEVICE uint32 per block of 256 consecutive Gaussians: the number of Gaussians with radii > 0 in
+ *                       the blocks before it (the caller has the visible set since the forward; it is read when the
+ *                       per-Gaussian kernel runs, i.e. it may still be in flight on `stream` when the call is issued)
+ * Only for first_view != 0 (a later view of a batch updates the sums of rows it sees, not of every row); packed == NULL
+ * or packed->rows == NULL: exactly g4s_rasterizer_backward_accumulate.
+ */
+typedef struct g4s_packed_rows {
+    float* rows;
+    const uint32_t* block_offs;
+    long long capacity;
+} g4s_packed_rows;
+int g4s_rasterizer_backward_accumulate_packed(
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* sh_dc, const float* sh_rest,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    char* geom_buffer, char* binning_buffer, char* image_buffer,
+    const float* dL_dpix, const float* dL_depths,
+    float* dL_dmean2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D,
+    float* dL_dtransMat, float* dL_dsh_dc, float* dL_dsh_rest, float* dL_dscale, float* dL_drot,
+    float* view_stats, int first_view, const g4s_packed_rows* packed,
+    char* workspace, size_t workspace_bytes, void* after_event, int debug, void* stream);
+
+/*
  * The forward WITHOUT its host synchronisation (extension; same results as g4s_rasterizer_forward[_split_sh]).
  * The reference -- and the two entry points above -- read num_rendered back to size the binning chunk
  * (rasterizer_impl.cu:281-282): the host stalls until the GPU has drained everything queued before the call, every

@@ -109,6 +109,89 @@ def test_owner_reduce_device_path_with_two_ranks_on_one_gpu():
                 assert 0.3 * nvis < sent < 0.7 * nvis  # about half of a rank's visible rows belong to the other owner
 
 
+def _prepack_worker(rank, world, port, q):
+    root = os.path.dirname(HERE)
+    for p in (root, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from g4splat_amd import synthetic
+    from g4splat_amd.diff_surfel_rasterization import _C
+    from g4splat_amd.parallel import OwnerReduce
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    P, W, H, D = 40_001, 320, 200, 3   # (a ragged last 256-block and a ragged last shard)
+    scene = synthetic.scene_room(P, seed=2)
+    cam = synthetic.room_cameras(4, W, H, fovx_deg=90.0)[rank]  # every rank its own view of the replicated scene
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    m3, sc, rot, opa, sh = t(scene.means3D), t(scene.scales), t(scene.rotations), t(scene.opacities), t(scene.shs)
+    view, proj, campos = t(cam.world_view_transform), t(cam.full_proj_transform), t(cam.camera_center)
+    bg, empty = torch.zeros(3, device=dev), torch.empty(0, device=dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    gc, go = torch.randn((3, H, W), device=dev, generator=g), torch.randn((7, H, W), device=dev, generator=g)
+    fw = _C.rasterize_gaussians(bg, m3, empty, opa, sc, rot, 1.0, empty, view, proj, cam.tanfovx, cam.tanfovy, H, W, sh, D,
+                                campos, False, False)
+    R, _c, _o, radii, geom, binning, img = fw
+    vis = radii > 0
+
+    def exchange(prepacked):
+        grads = dict(dL_dmeans3D=torch.zeros(P, 3, device=dev), dL_dsh=torch.zeros(P, 16, 3, device=dev),
+                     dL_dopacity=torch.zeros(P, 1, device=dev), dL_dscales=torch.zeros(P, 2, device=dev),
+                     dL_drotations=torch.zeros(P, 4, device=dev))
+        side = torch.zeros(P, 2, device=dev)
+        rows = [v.view(P, -1) for v in grads.values()] + [side]
+        red = OwnerReduce(rows)
+        red.begin(vis, radii=radii)
+        out = dict(grads, accumulate="first", view_stats=side)
+        if prepacked:
+            out["packed"] = red.prepack(vis)
+        _C.rasterize_gaussians_backward(bg, m3, radii, empty, sc, rot, 1.0, empty, view, proj, cam.tanfovx, cam.tanfovy, gc, go,
+                                        sh, D, campos, geom, R, binning, img, False, out=out)
+        packed_ok = None
+        if prepacked:  # the rows the kernel wrote == what the pack launch makes of the tensors (mode 10), bit for bit
+            n = int(vis.sum())
+            idx = vis.nonzero(as_tuple=True)[0]
+            want = torch.empty(n, red.width + 1, device=dev)
+            red._rows_kernel(idx, n, want, 10)
+            packed_ok = bool(torch.equal(out["packed"][0][:n].view(torch.int32), want.view(torch.int32))) and n > 1000
+        red.finish(prepacked=prepacked)
+        torch.cuda.synchronize()
+        return rows, packed_ok, red
+
+    rows_a, _, red_a = exchange(False)
+    rows_b, packed_ok, red_b = exchange(True)
+    same = all(bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(rows_a, rows_b))
+    q.put((rank, same, packed_ok, bool(red_b.last_prepacked), int(red_a.last_rows_sent), int(red_b.last_rows_sent),
+           float(rows_b[0].abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_backward_writes_the_exchange_rows_itself_and_the_exchange_is_unchanged():
+    """Verdict r4 item 2(a): with `out["packed"]` the per-Gaussian kernel of the backward leaves this rank's visible rows in
+    the owner exchange's send layout (g4s_rasterizer_backward_accumulate_packed), and OwnerReduce.finish(prepacked=True)
+    sends from there without its pack launch.  Two gloo ranks on cuda:0, each with its own view of a replicated 40 k-surfel
+    room: the rows the kernel wrote equal the pack launch's output bit for bit, and after the exchange every gradient
+    tensor and the statistics hold the same bits as with the pack launch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36900 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_prepack_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, packed_ok, flagged, sent_a, sent_b, mass in got:
+        assert packed_ok, rank
+        assert same, rank
+        assert flagged and sent_a == sent_b > 0 and mass > 0
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
     """`python bench.py --gpus 2` as ONE command (it starts its own ranks through torch.distributed.run): the N > 1 path
@@ -137,7 +220,9 @@ def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
     assert d["config"]["exchange_ms_per_step"] > 0
     ex = d["exchange"]
     assert ex["rccl_ranks"] == 2 and ex["backend"] == "gloo" and ex["ran"].startswith("owner-reduce") and ex["why"] == "default"
-    assert set(ex["ms_pieces"]) >= {"begin_local", "max_all_reduce", "pack", "all_to_all", "accumulate", "all_gather"}
+    assert ex["prepacked"] is (scaling == "weak") and ex["replicas_identical"] is True
+    assert set(ex["ms_pieces"]) >= {"begin_local", "max_all_reduce", "all_to_all", "accumulate", "all_gather"}
+    assert ("pack" in ex["ms_pieces"]) == (scaling == "strong")  # weak: the backward wrote the send rows itself
     assert ex["bytes_per_rank"]["all_to_all_sent"] > 0 and ex["bytes_per_rank"]["all_gather_received"] > 0
     t = d["timing"]
     assert len(t["per_step_ms"]) == 3 and t["mean_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
@@ -179,7 +264,8 @@ def test_bench_eight_ranks_control_flow_on_one_gpu(scaling, exchange):
     assert ex["rccl_ranks"] == 8 and ex["backend"] == "gloo"
     if exchange == "owner":
         assert ex["ran"].startswith("owner-reduce") and ex["why"] == "default"
-        assert set(ex["ms_pieces"]) >= {"begin_local", "max_all_reduce", "pack", "all_to_all", "accumulate", "all_gather"}
+        assert set(ex["ms_pieces"]) >= {"begin_local", "max_all_reduce", "all_to_all", "accumulate", "all_gather"}
+        assert ex["prepacked"] is (scaling == "weak")
         assert ex["bytes_per_rank"]["all_to_all_sent"] > 0 and ex["bytes_per_rank"]["all_gather_received"] > 0
         assert ex["buffer_allocations_after_warmup"] == 0, ex
     else:

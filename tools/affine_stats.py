@@ -23,7 +23,9 @@ def report(tag, inp):
     tt = st["tiles_touched"].astype(np.int64)
     binned = tt > 0
     print(f"{tag}: visible {int(vis.sum())}, binned {int(binned.sum())}, affine {int(aff.sum())} "
-          f"= {aff.sum() / max(1, binned.sum()):.4f} of the binned splats, {tt[aff].sum() / max(1, tt.sum()):.4f} of the instances", flush=True)
+          f"= {aff.sum() / max(1, binned.sum()):.4f} of the binned splats, {tt[aff].sum() / max(1, tt.sum()):.4f} of the instances; "
+          f"binned into ONE tile: {(tt == 1).sum() / max(1, binned.sum()):.4f} of the binned splats, into <= 4: "
+          f"{((tt > 0) & (tt <= 4)).sum() / max(1, binned.sum()):.4f}; instances per binned splat {tt.sum() / max(1, binned.sum()):.1f}", flush=True)
 
 
 which = set(sys.argv[1:]) or {"s1", "s2", "s3"}
