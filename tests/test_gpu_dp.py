@@ -192,7 +192,9 @@ def test_backward_writes_the_exchange_rows_itself_and_the_exchange_is_unchanged(
         assert flagged and sent_a == sent_b > 0 and mass > 0
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+# (strong scaling at two ranks -- four views per rank accumulated locally -- moved behind `-m "gpu and exhaustive"` in round 5:
+# the default suite runs strong scaling at eight ranks now, test_bench_eight_ranks_control_flow_on_one_gpu)
+@pytest.mark.parametrize("scaling", ["weak", pytest.param("strong", marks=pytest.mark.exhaustive)])
 def test_bench_two_ranks_control_flow_on_one_gpu(scaling):
     """`python bench.py --gpus 2` as ONE command (it starts its own ranks through torch.distributed.run): the N > 1 path
     end to end (launcher, warm-up fallback logic, owner-reduce exchange inside the timed steps, max-over-ranks timing,
