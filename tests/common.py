@@ -294,7 +294,11 @@ def assert_parity(h, o, inp, oracle_mod, tag="", out_atol=OUT_ATOL_GUARD, grad_r
     N = rep["N"]
     assert rep["out_err_unexplained"] <= out_atol, (tag, "output beyond the bar on a pixel that is on no threshold", rep)
     assert rep["id_mismatch_unexplained"] == 0, (tag, "contributor mismatch on a pixel that is on no threshold", rep)
-    assert rep["flipped_pixels"] <= max(2, max_flipped_frac * N), (tag, "too many threshold flips", rep)
+    # how many pixels may flip: a share of the frame -- or, where the lists are so deep that a frame has thousands of
+    # near-threshold decisions (tools/fuzz_sweep.py seed 90360: 12 instances per pixel, 3.3 % of the pixels within MARGIN, five of
+    # them flipped at margins <= 1.2e-7), 2 % of the pixels that sit within MARGIN of a threshold: a HIP error of the order of
+    # MARGIN itself would flip half of them.  (Every flipped pixel is checked against the oracle's alternative below.)
+    assert rep["flipped_pixels"] <= max(2, max_flipped_frac * N, 0.02 * rep["suspect_pixels"]), (tag, "too many threshold flips", rep)
     assert rep["flipped_unmatched"] == 0, (tag, "a flipped pixel's contributors match none of the oracle's alternatives", rep)
     assert rep["flipped_alt_err"] <= out_atol, (tag, "a flipped pixel is not the oracle's pixel with the decision taken the other way", rep)
     for name, g in rep.get("grads", {}).items():
