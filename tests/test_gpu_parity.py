@@ -460,9 +460,9 @@ def test_ten_million_gaussians_most_of_them_out_of_sight(hip_lib):
         assert not g[pad].any(), n
 
 
-@pytest.mark.parametrize("block", range(20))
+@pytest.mark.parametrize("block", [pytest.param(b, marks=() if b < 16 else pytest.mark.exhaustive) for b in range(20)])
 def test_fuzz_small_scenes(hip_lib, oracle_mod, block):
-    """Two hundred seeded random configurations (image sizes that are not multiples of the tile, 1-pixel-high images,
+    """Two hundred seeded random configurations (160 in the default run, the last four blocks behind `exhaustive`) (image sizes that are not multiples of the tile, 1-pixel-high images,
     huge and tiny splats, translucent and opaque, every SH degree, scale modifiers, backgrounds, fields of view)
     against the oracle: outputs, radii, instance counts, culled tile lists, gradients.  Frames this small take the
     four-wave backward under the default policy; every other case is run a second time with the one-wave-per-tile kernel
@@ -696,7 +696,9 @@ def test_largest_tile_grids(hip_lib, oracle_mod, side):
     g = cotangents(side, side, seed=6)
     o = run_oracle(oracle_mod, inp, g)
     h = run_hip(inp, g)
-    assert_parity(h, o, inp, oracle_mod, tag=f"{side}x{side}")
+    # (masked_rerun=False: the second backward over 17 M pixels with the suspect pixels' cotangents zeroed is the metric-size
+    # tests' job; this one is about tile ids beyond 16 bits)
+    assert_parity(h, o, inp, oracle_mod, tag=f"{side}x{side}", masked_rerun=False)
     assert np.median(np.abs(h["color"] - o["color"])) <= 1e-6
     if side > 4096:
         st = hip_state(h, inp)
