@@ -196,26 +196,90 @@ __device__ __forceinline__ void alpha_cutoff_ellipse(const float* T, float opa, 
 // Parts (b) and (c) of the REC_AFFINE certificate (g4s_device.h): true if the interpolated depth cannot fall below the
 // near plane where the splat passes the alpha test and the low-pass exponent rho2d can never be the smaller one where
 // it matters -- at every integer pixel whose rho2d could still pass the alpha test (a disk of <= 2.4 px around the
-// centre, <= 25 pixels) the 3-D exponent is smaller and outside the tie band -- evaluated with the blend loops' own
-// affine arithmetic (eval_rho_affine).
-__device__ __forceinline__ bool lowpass_never_matters(const float* T, const SplatAffine& af, float cx, float cy, float opa) {
-    const float thr = 2.0f * logf(255.0f * opa);
-    if (!(thr > 0.0f) || !(fabsf(cx) < 1e7f) || !(fabsf(cy) < 1e7f)) return false;
-    const float tt = thr * 1.01f + 0.1f;
-    // depth = s.x Tw.x + s.y Tw.y + Tw.z with |s|^2 <= t wherever alpha passes: never below the near plane?
-    if (!(T[8] - sqrtf(tt) * sqrtf(T[6] * T[6] + T[7] * T[7]) > NEAR_N * 1.05f)) return false;
+// centre: a box of at most 5 x 5 pixels) the 3-D exponent is smaller and outside the tie band -- evaluated with the
+// blend loops' own affine arithmetic (eval_rho_affine).
+//
+// Wave-cooperative: EVERY lane of the wave calls it (converged), `want` = this lane has a splat that passed part (a).
+// A quarter of the lanes carry such a splat (the rest are culled), each with up to 25 pixels to look at; walked by the
+// owning lane alone that is a 25-trip loop for the whole wave.  Here the splats of the wave are parked in LDS, 25 slots
+// each, and all 64 lanes take (splat, pixel) pairs: ~7 trips instead of 25 (preprocess_fwd 0.100 -> see DESIGN section 7).
+// s_par: 64 x 16 words of this wave, s_fail: 64 words of this wave.  The pixels visited and the arithmetic per pixel
+// are those of the serial walk, so the decision is the same bit.
+constexpr int CERT_SLOT_WORDS = 16;
+__device__ __forceinline__ bool lowpass_never_matters_wave(bool want, const float* T, const SplatAffine& af, float cx, float cy,
+                                                           float opa, float* s_par, uint32_t* s_fail) {
+    float tt = 0.0f;
+    if (want) {
+        const float thr = 2.0f * logf(255.0f * opa);
+        want = thr > 0.0f && fabsf(cx) < 1e7f && fabsf(cy) < 1e7f;
+        tt = thr * 1.01f + 0.1f;
+        // depth = s.x Tw.x + s.y Tw.y + Tw.z with |s|^2 <= t wherever alpha passes: never below the near plane?
+        if (want) want = T[8] - sqrtf(tt) * sqrtf(T[6] * T[6] + T[7] * T[7]) > NEAR_N * 1.05f;
+    }
     const float r = sqrtf(0.5f * tt) + 0.01f;
-    for (int yy = (int)ceilf(cy - r); yy <= (int)floorf(cy + r); yy++)
-        for (int xx = (int)ceilf(cx - r); xx <= (int)floorf(cx + r); xx++) {
-            const float ddx = (float)xx - cx, ddy = (float)yy - cy;
-            if (FILTER_INV_SQUARE * fmaf(ddx, ddx, ddy * ddy) > tt) continue;  // eval_rho_affine's rho2d, before the costly part
-            PairEval e;
-            bool tie;
-            if (!eval_rho_affine((float)xx, (float)yy, cx, cy, af, e, tie)) continue;
-            if (e.rho2d > tt) continue;
-            if (tie || !(e.rho3d <= e.rho2d)) return false;
+    const int xlo = (int)ceilf(cx - r), ylo = (int)ceilf(cy - r), xhi = (int)floorf(cx + r), yhi = (int)floorf(cy + r);
+    // opacity <= 1 gives r <= 2.39, i.e. at most 5 x 5 pixels; a caller's opacity above 1 simply does not qualify
+    if (want) want = xhi - xlo <= 4 && yhi - ylo <= 4;
+    // Most splats are much larger than the low-pass disk, and for those no pixel needs to be looked at:  with
+    // N(d) = (p'.x, p'.y) = N0 + M d and p'.z(d) = Dc'.z + (A'.z, B'.z) . d,  |N| <= |N0| + |M|_F |d| and
+    // |p'.z| >= zmin := |Dc'.z| - |(A'.z, B'.z)| r on the disk, so  rho3d = |N|^2 / p'.z^2 <= rho2d / 2 = (F / 2) |d|^2
+    // wherever |N0| + |M|_F |d| <= sqrt(F / 2) zmin |d|, i.e. for every pixel at |d| >= dmin (the nearest integer pixel)
+    // once  sqrt(F / 2) zmin > |M|_F  and  |N0| <= (sqrt(F / 2) zmin - |M|_F) dmin.  A factor of two between the
+    // exponents is far outside the tie band and outside anything the float evaluation can move (part (a): 4e-5), so
+    // the walk below would pass: `sure`.  The walk itself is left to the few splats this bound cannot decide.
+    bool sure = false;
+    if (want) {
+        const float kf = sqrtf(0.5f * FILTER_INV_SQUARE);
+        const float zmin = fabsf(af.Dc[2]) - sqrtf(fmaf(af.A[2], af.A[2], af.B[2] * af.B[2])) * r;
+        const float mf = sqrtf(fmaf(af.A[0], af.A[0], af.B[0] * af.B[0]) + fmaf(af.A[1], af.A[1], af.B[1] * af.B[1]));
+        const float n0 = sqrtf(fmaf(af.Dc[0], af.Dc[0], af.Dc[1] * af.Dc[1]));
+        const float fx = cx - floorf(cx), fy = cy - floorf(cy);
+        const float dxm = fminf(fx, 1.0f - fx), dym = fminf(fy, 1.0f - fy);
+        const float dmin = sqrtf(fmaf(dxm, dxm, dym * dym));
+        const float slack = kf * zmin - mf;  // (NaN anywhere fails the comparisons)
+        sure = slack > 0.0f && dmin >= 1e-3f && n0 <= 0.99f * slack * dmin;
+    }
+    const bool walk = want && !sure;
+    const uint64_t m = __ballot(walk);
+    if (m == 0) return want;  // (uniform)
+    const int lane = lane_id();
+    const int rank = (int)__popcll(m & lanes_below_mask());
+    if (walk) {
+        float4* q = reinterpret_cast<float4*>(s_par + rank * CERT_SLOT_WORDS);
+        q[0] = make_float4(af.A[0], af.A[1], af.A[2], af.B[0]);
+        q[1] = make_float4(af.B[1], af.B[2], af.Dc[0], af.Dc[1]);
+        q[2] = make_float4(af.Dc[2], cx, cy, tt);
+        q[3] = make_float4(__int_as_float(xlo), __int_as_float(ylo), __int_as_float(xhi), __int_as_float(yhi));
+        s_fail[rank] = 0u;
+    }
+    __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order; this only pins the compiler's)
+    const int total = 25 * (int)__popcll(m);
+    for (int base = 0; base < total; base += 64) {  // (uniform)
+        const int i = base + lane;
+        if (i < total) {
+            const int rk = i / 25, pix = i - 25 * rk, iy = pix / 5, ix = pix - 5 * iy;
+            const float4* q = reinterpret_cast<const float4*>(s_par + rk * CERT_SLOT_WORDS);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const int xx = __float_as_int(q3.x) + ix, yy = __float_as_int(q3.y) + iy;
+            if (xx <= __float_as_int(q3.z) && yy <= __float_as_int(q3.w)) {
+                SplatAffine f;
+                f.A[0] = q0.x; f.A[1] = q0.y; f.A[2] = q0.z;
+                f.B[0] = q0.w; f.B[1] = q1.x; f.B[2] = q1.y;
+                f.Dc[0] = q1.z; f.Dc[1] = q1.w; f.Dc[2] = q2.x;
+                const float scx = q2.y, scy = q2.z, stt = q2.w;
+                const float ddx = (float)xx - scx, ddy = (float)yy - scy;
+                if (!(FILTER_INV_SQUARE * fmaf(ddx, ddx, ddy * ddy) > stt)) {  // eval_rho_affine's rho2d, before the costly part
+                    PairEval e;
+                    bool tie;
+                    if (eval_rho_affine((float)xx, (float)yy, scx, scy, f, e, tie) && !(e.rho2d > stt) &&
+                        (tie || !(e.rho3d <= e.rho2d)))
+                        s_fail[rk] = 1u;
+                }
+            }
         }
-    return true;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return want && (sure || s_fail[rank] == 0u);
 }
 
 // Loads the 3*(deg+1)^2 active SH floats of Gaussian idx into registers.  vec16: the records are
@@ -320,21 +384,26 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* sh, F3 pos, F3 c
 // (6 waves = 80 VGPRs spill 80 registers: 0.125 ms, LAB_NOTES section 3.)
 template <int SH_MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) preprocess_fwd_kernel(PreprocessArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_cert[4][64 * CERT_SLOT_WORDS];
+    __shared__ uint32_t s_cert_fail[4][64];
     const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
     const bool in_range = idx < a.P;
     int radius_out = 0;
     uint32_t touched_ref = 0, touched = 0, key = CULLED_KEY, clamp_bits = 0;
-    float rec[REC_FLOATS];
-#pragma unroll
-    for (int i = 0; i < REC_FLOATS; i++) rec[i] = 0.0f;
-    rec[20] = __uint_as_float(1u);  // empty box: x0 = 1 > x1 = 0
+    // What a Gaussian that reaches the innermost block below hands to the two steps behind the joins (the wave-wide
+    // certificate and the record store).  Deliberately NOT initialised: they are read only where radius_out > 0 says they
+    // were written, and a zero on the culled paths would cost a register copy per word at each of the five joins.
+    float T[9], cx, cy, opa, rgb[3];
+    F3 normal;
+    float4 box;
+    int tx0, ty0, tx1, ty1;
+    SplatAffine af;
+    bool want = false;  // part (a) of the REC_AFFINE certificate holds (g4s_device.h)
 
     if (in_range) {
         const F3 p = mk3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         const F3 p_view = xform_point_4x3(p, a.viewmatrix);
         if (p_view.z > 0.2f) {  // in_frustum, auxiliary.h:184-209
-            float T[9];
-            F3 normal;
             if (a.transMat_precomp == nullptr) {
                 float R[9];
                 const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
@@ -347,21 +416,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
                 for (int i = 0; i < 9; i++) T[i] = a.transMat_precomp[9 * (size_t)idx + i];
                 normal = mk3(0.0f, 0.0f, 1.0f);
             }
-            // T is kept even if the Gaussian is culled below (forward.cu:197-200); REC_AFFINE splats replace it by p'
-#pragma unroll
-            for (int i = 0; i < 9; i++) rec[8 + i] = T[i];
             const float cosv = -((p_view.x * normal.x + p_view.y * normal.y) + p_view.z * normal.z);
             if (cosv != 0) {
                 const float mult = cosv > 0 ? 1.0f : -1.0f;
                 normal = mk3(mult * normal.x, mult * normal.y, mult * normal.z);
-                float cx, cy, ex, ey;
+                float ex, ey;
                 if (compute_aabb(T, 3.0f, cx, cy, ex, ey)) {
                     const float radius = ceilf(fmaxf(ex, ey));
                     int x0, y0, x1, y1;
                     get_rect(cx, cy, sat_int(radius), a.tiles_x, a.tiles_y, x0, y0, x1, y1);
                     const int area = (x1 - x0) * (y1 - y0);
                     if (area != 0) {
-                        float rgb[3];
                         if (a.colors_precomp == nullptr) {
                             float sh[48];
                             load_sh(a.shs, SH_MODE == 2 ? a.shs_rest : nullptr, (size_t)idx, a.M, a.D, SH_MODE == 0, sh);
@@ -371,68 +436,63 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
                             rgb[1] = a.colors_precomp[3 * (size_t)idx + 1];
                             rgb[2] = a.colors_precomp[3 * (size_t)idx + 2];
                         }
-                        const float opa = a.opacities[idx];
+                        opa = a.opacities[idx];
                         radius_out = sat_int(radius);
                         touched_ref = (uint32_t)area;
                         key = __float_as_uint(p_view.z);
-                        float4 box;
                         alpha_cutoff_box(T, cx, cy, opa, box);
-                        int tx0, ty0, tx1, ty1;
                         tight_tile_rect(box, x0, y0, x1, y1, tx0, ty0, tx1, ty1);
                         touched = (uint32_t)((tx1 - tx0) * (ty1 - ty0));
                         // the emit kernel expands exactly this rect: 8 bytes per Gaussian instead of two record quads + radius
                         if (touched != 0) a.tight_rect[idx] = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)(tx1 - tx0));
-                        rec[0] = cx;
-                        rec[1] = cy;
-                        // q0.w = binned rect (width | height << 16) | REC_AFFINE; q7.w = its origin (x0 | y0 << 16)
-                        // Does the splat qualify for the affine ray-splat intersection (REC_AFFINE, g4s_device.h)?  Then
-                        // quads 2..4 carry A', B', Dc' instead of T.  Only splats that are binned can be asked for it.
-                        bool affine = false;
+                        // Does the splat qualify for the affine ray-splat intersection (REC_AFFINE, g4s_device.h)?  Part (a)
+                        // here; only splats that are binned can be asked for it.
                         if (touched != 0 && !a.no_fastpath) {
                             // how far from the centre the splat is evaluated with a chance to pass: its alpha-cutoff box, in the frame
                             const float bx0 = fmaxf(box.x, 0.0f), bx1 = fminf(box.z, (float)(a.W - 1));
                             const float by0 = fmaxf(box.y, 0.0f), by1 = fminf(box.w, (float)(a.H - 1));
                             const float ex = fmaxf(fabsf(bx0 - cx), fabsf(bx1 - cx)), ey = fmaxf(fabsf(by0 - cy), fabsf(by1 - cy));
                             const float smax = sqrtf(2.0f * logf(255.0f * opa) * 1.001f + 1e-3f);
-                            SplatAffine af;
                             splat_affine(T, cx, cy, ex, ey, smax, af);
-                            affine = af.ok && lowpass_never_matters(T, af, cx, cy, opa);
-                            if (affine) {
-#pragma unroll
-                                for (int i = 0; i < 3; i++) {
-                                    rec[8 + i] = af.A[i];
-                                    rec[11 + i] = af.B[i];
-                                    rec[14 + i] = af.Dc[i];
-                                }
-                            }
+                            want = af.ok;
                         }
-                        rec[3] = __uint_as_float(rect_extent_word(tx1 - tx0, ty1 - ty0) | (affine ? REC_AFFINE : 0u));
-                        rec[4] = normal.x;
-                        rec[5] = normal.y;
-                        rec[6] = normal.z;
-                        rec[7] = opa;
-                        rec[17] = rgb[0];
-                        rec[18] = rgb[1];
-                        rec[19] = rgb[2];
-                        uint32_t bx0, bx1, by0, by1;
-                        box_quadrants(box.x, box.z, a.W, bx0, bx1);
-                        box_quadrants(box.y, box.w, a.H, by0, by1);
-                        rec[20] = __uint_as_float(bx0);
-                        rec[21] = __uint_as_float(bx1);
-                        rec[22] = T[8];
-                        rec[23] = __uint_as_float(by0 | (by1 << 16));
-                        if (touched != 0) alpha_cutoff_ellipse(T, opa, rec + 24);  // rec[28] (1 / a^2) stays 0 when there is no ellipse
-                        rec[31] = __uint_as_float((uint32_t)tx0 | ((uint32_t)ty0 << 16));
                     }
                 }
             }
         }
-        // the record of a Gaussian with radii == 0 is never read (emit / blend follow the tile lists, the backward
-        // looks at radii first): writing only the visible ones saves 128 B x (P - V) of stores
+    }
+    // parts (b) and (c), all lanes of the wave together
+    const bool affine = lowpass_never_matters_wave(want, T, af, cx, cy, opa, s_cert[threadIdx.x >> 6], s_cert_fail[threadIdx.x >> 6]);
+    if (in_range) {
+        // The record of a Gaussian with radii == 0 is never read (emit / blend follow the tile lists, the backward looks
+        // at radii first): writing only the visible ones saves 128 B x (P - V) of stores.
         if (radius_out > 0) {
-            float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * REC_QUADS;
+            // q0.w = binned rect (width | height << 16) | REC_AFFINE; q2..q4 = T (forward.cu:197-200), or A', B', Dc' for
+            // REC_AFFINE splats; q7.w = the rect's origin (x0 | y0 << 16)
+            float c[9];
 #pragma unroll
-            for (int i = 0; i < REC_QUADS; i++) out[i] = make_float4(rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]);
+            for (int i = 0; i < 3; i++) {  // selects, not a branch: no copies of the nine words at a join
+                c[i] = affine ? af.A[i] : T[i];
+                c[3 + i] = affine ? af.B[i] : T[3 + i];
+                c[6 + i] = affine ? af.Dc[i] : T[6 + i];
+            }
+            uint32_t bx0, bx1, by0, by1;
+            box_quadrants(box.x, box.z, a.W, bx0, bx1);
+            box_quadrants(box.y, box.w, a.H, by0, by1);
+            float ell[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) ell[i] = 0.0f;
+            if (touched != 0) alpha_cutoff_ellipse(T, opa, ell);  // ell[4] (1 / a^2) stays 0 when there is no ellipse
+            float4* out = reinterpret_cast<float4*>(a.rec) + (size_t)idx * REC_QUADS;
+            out[0] = make_float4(cx, cy, 0.0f /* inst_off: slots_and_compact_kernel */,
+                                 __uint_as_float(rect_extent_word(tx1 - tx0, ty1 - ty0) | (affine ? REC_AFFINE : 0u)));
+            out[1] = make_float4(normal.x, normal.y, normal.z, opa);
+            out[2] = make_float4(c[0], c[1], c[2], c[3]);
+            out[3] = make_float4(c[4], c[5], c[6], c[7]);
+            out[4] = make_float4(c[8], rgb[0], rgb[1], rgb[2]);
+            out[5] = make_float4(__uint_as_float(bx0), __uint_as_float(bx1), T[8], __uint_as_float(by0 | (by1 << 16)));
+            out[6] = make_float4(ell[0], ell[1], ell[2], ell[3]);
+            out[7] = make_float4(ell[4], ell[5], ell[6], __uint_as_float((uint32_t)tx0 | ((uint32_t)ty0 << 16)));
         }
         a.clamped[idx] = (uint8_t)clamp_bits;
         a.tiles_touched[idx] = touched;
