@@ -160,6 +160,12 @@ def main():
         dist.barrier()
     lib = _lib.load()
     build_id = lib.g4s_version().decode().split("build ")[-1]
+    # bring-up aid (never set by the driver): G4S_BENCH_OPTIONS="side_stream=0,..." -> g4s_set_option, for A/B runs
+    lib_options = {}
+    for kv in filter(None, os.environ.get("G4S_BENCH_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        _lib.set_option(k.strip(), int(v))
+        lib_options[k.strip()] = int(v)
     from g4splat_amd.diff_surfel_rasterization import _C
 
     scene, cams, dev, dcams, (P, W, H, D) = build_scene(args.workload, device)
@@ -663,6 +669,8 @@ def main():
         elapsed_events_s=elapsed_events, sustained=sustained, exchange_info=exchange_info, exchanged_rows=exchanged_rows,
         exchange_ms=exchange_ms, views_in_flight=vif, roofline=roofline, cpu_baseline=cpu_baseline, build_id=build_id,
         trained_scene=TRAINED_INFO.get(args.workload)))
+    if lib_options:
+        out["library_options"] = lib_options  # (an A/B run: not the library's defaults)
     print(json.dumps(out))
     sys.stdout.flush()
     if dist is not None:
