@@ -958,6 +958,30 @@ extern "C" int g4s_pack_rows(int nseg, float* const* segments, const int* widths
     return G4S_OK;
 }
 
+extern "C" int g4s_accumulate_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, int nsrc, const int* src_off,
+                                                   const int* src_cnt, const float* packed, int row_lo, int row_hi,
+                                                   hipStream_t s);
+
+extern "C" int g4s_accumulate_rows(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
+                                   const int* src_counts, const float* packed, int row_lo, int row_hi, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int debug = 0;
+    t_err[0] = 0;
+    if (nseg < 1 || nseg > 8 || nsrc < 0 || row_lo < 0 || row_hi < row_lo)
+        return fail(G4S_ERR_INVALID_ARGUMENT, "1..8 segments, nsrc >= 0, 0 <= row_lo <= row_hi");
+    if (!segments || !widths || (nsrc > 0 && (!src_offsets || !src_counts || !packed)))
+        return fail(G4S_ERR_INVALID_ARGUMENT, "NULL pointer");
+    for (int i = 0; i < nseg; i++)
+        if (!segments[i] || widths[i] <= 0) return fail(G4S_ERR_INVALID_ARGUMENT, "segment %d: NULL pointer or width <= 0", i);
+    for (int i = 0; i < nsrc; i++)
+        if (src_offsets[i] < 0 || src_counts[i] < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "source %d: negative offset / count", i);
+    if (nsrc == 0 || row_hi == row_lo) return G4S_OK;
+    if (g4s_accumulate_rows_launch_internal(nseg, segments, widths, nsrc, src_offsets, src_counts, packed, row_lo, row_hi, stream) != 0)
+        return fail(G4S_ERR_UNSUPPORTED, "rows wider than 240 floats");
+    CHECK_LAUNCH("accumulate_rows");
+    return G4S_OK;
+}
+
 // ---- fused render() map post-processing (include/g4s_render_maps.h) -------------------------------
 #include "../../include/g4s_render_maps.h"
 

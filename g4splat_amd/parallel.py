@@ -380,6 +380,27 @@ class OwnerReduce:
         if rc != 0:
             raise RuntimeError(f"g4s_pack_rows failed ({rc}): {_lib.last_error()}")
 
+    # sources from which the one-launch accumulation (a read + write of the whole shard) beats a launch per source
+    # (read + write of the arrived rows only): measured at the metric size, tools/micro/owner_local_cost.py
+    ONE_LAUNCH_SOURCES = 4
+
+    def _accumulate_kernel(self, offs, cnts, buf):
+        """g4s_accumulate_rows (include/g4s_rasterizer.h): the rows of `buf` received from the sources (offs[i], cnts[i]) are
+        added to my shard of the row views, source after source, in one launch."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        k, n = len(self.rows), len(offs)
+        ptrs = (ctypes.c_void_p * k)(*[r.data_ptr() for r in self.rows])
+        widths = (ctypes.c_int * k)(*self.widths)
+        lo, hi = self.bounds()
+        with torch.cuda.device(self.dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            rc = lib.g4s_accumulate_rows(k, ptrs, widths, n, (ctypes.c_int * n)(*offs), (ctypes.c_int * n)(*cnts),
+                                         ctypes.c_void_p(buf.data_ptr()), int(lo), int(hi), stream)
+        if rc != 0:
+            raise RuntimeError(f"g4s_accumulate_rows failed ({rc}): {_lib.last_error()}")
+
     def all_gather_rows(self, tensors: Sequence[torch.Tensor]):
         """All-gathers the owners' row ranges of contiguous [P, ...] tensors in place (equal shards), as one RCCL group
         where the backend can: on return every rank holds every owner's rows."""
@@ -488,18 +509,31 @@ class OwnerReduce:
             # source holds a row at most once => no duplicate indices inside one accumulation, and the order is fixed)
             o = 0
             with self._timed("accumulate"):
-                for s_ in range(self.world):
-                    c = recv[s_]
-                    if c and s_ != self.rank:  # (prepacked: my own rows came back to me; they are already in place)
-                        if self.hip:
-                            self._rows_kernel(None, c, in_rows[o:o + c], 15)
-                        else:
+                if self.hip:
+                    # one launch for all sources (g4s_accumulate_rows: the same additions in the same order as a launch
+                    # per source, one read + write of my shard instead of one per source); every source's rows ascend by
+                    # index -- the index list of begin() is sorted, and so are the rows the backward packs itself
+                    offs, cnts = [], []
+                    for s_ in range(self.world):
+                        if recv[s_] and s_ != self.rank:  # (prepacked: my own rows came back to me; they are already in place)
+                            offs.append(o)
+                            cnts.append(recv[s_])
+                        o += recv[s_]
+                    if len(offs) >= self.ONE_LAUNCH_SOURCES:
+                        self._accumulate_kernel(offs, cnts, in_rows)
+                    else:  # few sources: a launch each touches only the rows that arrived, not the whole shard
+                        for o_, c_ in zip(offs, cnts):
+                            self._rows_kernel(None, c_, in_rows[o_:o_ + c_], 15)
+                else:
+                    for s_ in range(self.world):
+                        c = recv[s_]
+                        if c and s_ != self.rank:
                             ridx = in_rows[o:o + c, W].contiguous().view(torch.int32).to(torch.int64)
                             off = 0
                             for r, w in zip(self.rows, self.widths):
                                 r.index_add_(0, ridx, in_rows[o:o + c, off:off + w])
                                 off += w
-                    o += c
+                        o += c
             if not gather:
                 return
             # every rank gets every reduced shard

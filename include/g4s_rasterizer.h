@@ -329,6 +329,17 @@ int g4s_get_option(const char* name, int* value);
 int g4s_pack_rows(int nseg, float* const* segments, const int* widths, const long long* row_index, int n,
                   float* packed, int mode, void* stream);
 
+/*
+ * The owner's side of that exchange in ONE launch (new functionality): `packed` holds, back to back, the row-major
+ * rows with index column (g4s_pack_rows mode bits 1 | 3 layout) received from `nsrc` sources -- source i's rows are
+ * [src_offsets[i], src_offsets[i] + src_counts[i]), every index in [row_lo, row_hi) (the owner's shard), ASCENDING inside
+ * a source and distinct inside a source.  Adds them to the segments' rows, source after source: element for element the
+ * same sequence of additions -- the same bits -- as one g4s_pack_rows(mode 15) call per source in that order, with one
+ * read and one write of the shard instead of one per source.  `src_offsets` / `src_counts` are HOST arrays.
+ */
+int g4s_accumulate_rows(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
+                        const int* src_counts, const float* packed, int row_lo, int row_hi, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py
  * for the roofline figure; off by default, process-wide).  Kernel groups 0..g4s_profile_kernels()-1
  * are named by g4s_profile_name().  g4s_profile_read() synchronises on the recorded events and

@@ -192,6 +192,74 @@ def test_backward_writes_the_exchange_rows_itself_and_the_exchange_is_unchanged(
         assert flagged and sent_a == sent_b > 0 and mass > 0
 
 
+def test_all_sources_accumulated_in_one_launch_equal_one_launch_per_source():
+    """g4s_accumulate_rows (the owner's side of the exchange as ONE launch: a workgroup per 64 destination rows, the
+    sources' rows of the chunk found by a 32-ary search over their ascending index columns) against what it replaces,
+    one g4s_pack_rows(mode 15) launch per source in the same order: bit-identical, and equal to the sequential float32
+    sums computed on the host.  Sources with no row, with one row, with every row of the shard, with rows at both ends of
+    the shard; shards whose length is not a multiple of 64; one to nine sources (nine = two launches)."""
+    import ctypes
+    import numpy as np
+    from g4splat_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    widths = (3, 48, 1, 2, 4, 2)
+    W = sum(widths)
+    k = len(widths)
+    wid = (ctypes.c_int * k)(*widths)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rng = np.random.default_rng(5)
+    for P, lo, hi, nsrc in ((50_000, 18_750, 25_000, 7), (50_000, 0, 6_250, 7), (50_001, 43_750, 50_001, 7),
+                            (1_000, 100, 137, 3), (1_000, 0, 1_000, 1), (30_000, 10_000, 20_000, 9), (300, 64, 128, 8)):
+        base = [torch.randn(P, w, device=dev) for w in widths]
+        counts = []
+        for s_ in range(nsrc):
+            n = hi - lo
+            counts.append([0, 1, n, int(n * 0.28), int(n * 0.28), 2, int(n * 0.5), int(n * 0.9), 3][s_ % 9])
+        idx = [np.sort(rng.choice(np.arange(lo, hi), c, replace=False)) for c in counts]
+        if counts[1 % nsrc] == 1 and nsrc > 1:
+            idx[1] = np.array([hi - 1])
+        if nsrc > 5:
+            idx[5] = np.array([lo, hi - 1])
+        m = sum(counts)
+        buf = torch.randn(max(m, 1), W + 1, device=dev)
+        flat = np.concatenate(idx) if m else np.zeros(0, np.int64)
+        if m:
+            buf[:m, W] = torch.as_tensor(flat.astype(np.int32), device=dev).view(torch.float32)
+        offs = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(int).tolist()
+
+        def per_source(rows):
+            ptrs = (ctypes.c_void_p * k)(*[r.data_ptr() for r in rows])
+            for o, c in zip(offs, counts):
+                if c:
+                    assert lib.g4s_pack_rows(k, ptrs, wid, None, c, ctypes.c_void_p(buf[o:o + c].data_ptr()), 15, stream) == 0
+
+        def one_launch(rows):
+            ptrs = (ctypes.c_void_p * k)(*[r.data_ptr() for r in rows])
+            live = [(o, c) for o, c in zip(offs, counts) if c]
+            n = len(live)
+            rc = lib.g4s_accumulate_rows(k, ptrs, wid, n, (ctypes.c_int * n)(*[o for o, _ in live]),
+                                         (ctypes.c_int * n)(*[c for _, c in live]), ctypes.c_void_p(buf.data_ptr()), lo, hi,
+                                         stream)
+            assert rc == 0, _lib.last_error()
+
+        a = [r.clone() for r in base]
+        b = [r.clone() for r in base]
+        per_source(a)
+        one_launch(b)
+        torch.cuda.synchronize()
+        host = [r.cpu().numpy().copy() for r in base]
+        hb = buf.cpu().numpy()
+        for o, c, ix in zip(offs, counts, idx):
+            off = 0
+            for r, w in zip(host, widths):
+                r[ix] = r[ix] + hb[o:o + c, off:off + w]  # (distinct indices inside a source)
+                off += w
+        for x, y, z in zip(a, b, host):
+            assert torch.equal(x, y), (P, lo, hi, nsrc)
+            assert np.array_equal(y.cpu().numpy(), z), (P, lo, hi, nsrc)
+
+
 # (strong scaling at two ranks -- four views per rank accumulated locally -- moved behind `-m "gpu and exhaustive"` in round 5:
 # the default suite runs strong scaling at eight ranks now, test_bench_eight_ranks_control_flow_on_one_gpu)
 @pytest.mark.parametrize("scaling", ["weak", pytest.param("strong", marks=pytest.mark.exhaustive)])

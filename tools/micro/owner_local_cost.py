@@ -61,15 +61,36 @@ in_idx = torch.randperm(shard, device=dev)[:max(1, per_src)].sort().values
 in_rows[:, W] = in_idx.to(torch.int32).view(torch.float32)
 
 
-def finish_local():  # persistent buffers: nothing is allocated here
-    if n:
+# all sources in one launch (g4s_accumulate_rows): the received rows of the world - 1 sources back to back, each source's
+# indices ascending inside this rank's shard [0, shard)
+all_rows = torch.randn(max(1, per_src * (world - 1)), W + 1, device=dev)
+for s_ in range(world - 1):
+    ii = torch.randperm(shard, device=dev)[:per_src].sort().values
+    all_rows[s_ * per_src:(s_ + 1) * per_src, W] = ii.to(torch.int32).view(torch.float32)
+src_off = (ctypes.c_int * max(1, world - 1))(*[s_ * per_src for s_ in range(world - 1)])
+src_cnt = (ctypes.c_int * max(1, world - 1))(*[per_src] * (world - 1))
+
+
+def accumulate_one_launch():
+    assert lib.g4s_accumulate_rows(k, ptrs, wid, world - 1, src_off, src_cnt, ctypes.c_void_p(all_rows.data_ptr()), 0, shard,
+                                   stream) == 0
+
+
+def finish_local(prepacked=False):  # persistent buffers: nothing is allocated here
+    if n and not prepacked:
         kernel(send_idx, n, buf, 10)
-    for _s in range(world - 1):
-        kernel(None, per_src, in_rows, 15)
+    if world - 1 >= 4:  # OwnerReduce.ONE_LAUNCH_SOURCES
+        accumulate_one_launch()
+    else:
+        for _s in range(world - 1):
+            kernel(None, per_src, in_rows, 15)
 
 
 print(f"world {world}: {n} rows to send, {per_src} rows per source to accumulate")
 print("begin (index list + counts)      %.3f ms" % t(begin))
 print("pack (one launch)                %.3f ms" % t(lambda: kernel(send_idx, n, buf, 10)))
 print("accumulate (world-1 launches)    %.3f ms" % t(lambda: [kernel(None, per_src, in_rows, 15) for _ in range(world - 1)]))
-print("finish, local part               %.3f ms" % t(finish_local))
+print("accumulate (one launch)          %.3f ms" % t(accumulate_one_launch))
+print("finish, local part               %.3f ms   (pack + the accumulation OwnerReduce picks: one launch from four sources on)" % t(finish_local))
+print("finish, local part, prepacked    %.3f ms   (the backward wrote the send rows: + %s ms in its per-Gaussian kernel,"
+      " profiles/r05_prepack_cost.txt)" % (t(lambda: finish_local(True)), "0.027-0.044"))
