@@ -403,11 +403,13 @@ __global__ void __launch_bounds__(256) emit_kernel(int V, uint32_t R_b, int tile
     }
     __syncthreads();
     const int nr = (int)s_nr;  // >= 1: rank r_first always qualifies
+    // bisection steps for nr candidates (uniform; at most 11: 2^11 > EMIT_SLOTS + 1 -- a window of near splats holds a
+    // handful of ranks, one of far ones a thousand)
+    const int steps = 32 - __builtin_clz((uint32_t)nr | 1u);
     for (uint32_t o = w0 + (uint32_t)t; o < w1; o += 256) {
         // largest j < nr with s_off[j] <= o
         int a = 0, b = nr - 1;
-#pragma unroll
-        for (int it = 0; it < 11; it++) {  // 2^11 > EMIT_SLOTS + 1
+        for (int it = 0; it < steps; it++) {
             const int mid = (a + b + 1) >> 1;
             if (s_off[mid] <= o) a = mid; else b = mid - 1;
         }

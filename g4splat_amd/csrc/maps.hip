@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256) accumulate_rows_kernel(RowSegs segs, AccS
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int f = lane + 64 * q;
-                    v[u][q] = (q == 0 || f < row_floats) && f < row_floats ? rowp[f] : 0.0f;
+                    v[u][q] = f < row_floats ? rowp[f] : 0.0f;
                 }
             }
 #pragma unroll
