@@ -1,4 +1,5 @@
-"""How well can the one-wave blend backward be balanced?  Per-tile cost model of the kernel (111 instructions per visit +
+"""How well can the one-wave blend backward be balanced -- in a slot model with a fixed speed per wave (which the hardware
+does not follow: LAB_NOTES section 5 has the measurement that contradicts the 1.2 x this prints for view 0)?  Per-tile cost model of the kernel (111 instructions per visit +
 78 per contributing entry, the key the tiles are ordered by) from the forward's contribution masks of a real frame, then a
 list-scheduling simulation: tiles in descending order onto `slots` wave slots (what the dispatcher does with the ordered
 grid) against the ideal total / slots.        python tools/tile_balance.py [view] [slots]"""
