@@ -565,6 +565,21 @@ def test_shortcuts_never_change_a_result(hip_lib, switch):
         assert np.array_equal(x, y)
 
 
+def test_opacities_above_one(hip_lib, oracle_mod):
+    """The reference clamps alpha = min(0.99, opacity * G) and accepts any opacity a caller hands in.  Above 1 the region
+    where the low-pass exponent could still pass the alpha test outgrows the 5 x 5 pixels the REC_AFFINE certificate's
+    cooperative walk parks per splat (csrc/preprocess.hip: lowpass_never_matters_wave): such splats must fall back to the
+    reference's arithmetic, not be certified on a partial walk.  Small and sub-pixel splats, where the low-pass matters."""
+    for seed, scale_mul in ((31, 0.05), (32, 0.2), (33, 1.0), (34, 0.02)):
+        inp = scene_inputs(P=4000, W=200, H=120, seed=seed, D=2, scale_mul=scale_mul)
+        inp["opacity"] = (inp["opacity"] * 6.0).astype(np.float32)
+        assert float(inp["opacity"].max()) > 3.0
+        g = cotangents(inp["H"], inp["W"], seed=seed)
+        o = run_oracle(oracle_mod, inp, g)
+        h = run_hip(inp, g)
+        assert_parity(h, o, inp, oracle_mod, tag=f"opacity <= 6, seed {seed}")
+
+
 def test_hot_tiles(hip_lib, oracle_mod):
     """Everything lands in a handful of tiles (lists of ~10^4 translucent instances each, far more than one staging
     batch; no early saturation): the long-list paths of both blend kernels and of the per-Gaussian fold."""
