@@ -120,6 +120,19 @@ def test_argument_validation_is_host_side(hip_lib):
            "resize callbacks")
     expect(lib.g4s_rasterizer_forward(cb, nul, cb, nul, cb, nul, 10, 3, 16, one, 0, 32, one, one, nul, *fwd_tail),
            "must be positive")
+    # the owner's accumulation of the exchange (g4s_accumulate_rows)
+    segs = (ctypes.c_void_p * 2)(256, 512)
+    wid = (ctypes.c_int * 2)(3, 48)
+    off, cnt = (ctypes.c_int * 1)(0), (ctypes.c_int * 1)(5)
+    expect(lib.g4s_accumulate_rows(0, segs, wid, 1, off, cnt, one, 0, 64, nul), "1..8 segments")
+    expect(lib.g4s_accumulate_rows(2, segs, wid, 1, off, cnt, one, 64, 0, nul), "row_lo <= row_hi")
+    expect(lib.g4s_accumulate_rows(2, segs, wid, 1, off, cnt, nul, 0, 64, nul), "NULL pointer")
+    expect(lib.g4s_accumulate_rows(2, segs, wid, 1, (ctypes.c_int * 1)(-1), cnt, one, 0, 64, nul), "negative offset")
+    assert lib.g4s_accumulate_rows(2, segs, wid, 0, nul, nul, nul, 0, 64, nul) == 0   # no source: nothing to do
+    assert lib.g4s_accumulate_rows(2, segs, wid, 1, off, cnt, one, 64, 64, nul) == 0  # empty shard: nothing to do
+    wide = (ctypes.c_int * 2)(200, 48)
+    rc = lib.g4s_accumulate_rows(2, segs, wide, 1, off, cnt, one, 0, 64, nul)
+    assert rc < 0 and b"wider than 240" in lib.g4s_last_error()
 
 
 def _layout(lib, P, R, W, H):
