@@ -650,6 +650,23 @@ def main():
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
         cpu_baseline = run_cpu_baseline(scene, cams[0], P, W, H, D)
+        ref_maps = cpu_baseline.pop("_maps", None)
+        if ref_maps is not None:
+            # The oracle has just rendered the WHOLE scene from view 0 (its timed sample): the checker's use of it.  The
+            # contract read literally -- north_star: "RGB/depth/normal to <= 1e-4 abs" -- on that frame: how many pixels
+            # of the HIP forward lie beyond 1e-4 in any of the ten maps, and the worst of them (they are threshold flips:
+            # tests/common.py proves each one equal to the oracle's own pixel with that decision taken the other way).
+            c0 = dcams[0]
+            fw = _C.rasterize_gaussians(torch.zeros(3, device=device), dev["means3D"], empty, dev["opacity"], dev["scales"],
+                                        dev["rotations"], 1.0, empty, c0["view"], c0["proj"], c0["tanfovx"], c0["tanfovy"], H, W,
+                                        dev["sh"], D, c0["campos"], False, False)
+            import numpy as np
+            dmax = np.maximum(np.abs(fw[1].cpu().numpy() - ref_maps[0]).max(axis=0), np.abs(fw[2].cpu().numpy() - ref_maps[1]).max(axis=0))
+            cpu_baseline["checker"] = {"frame": f"view 0, {W}x{H}, all {P} surfels", "pixels": int(dmax.size),
+                                       "pixels_beyond_1e-4_abs": int((dmax > 1e-4).sum()),
+                                       "frac_beyond_1e-4_abs": float((dmax > 1e-4).mean()), "worst_abs": float(dmax.max()),
+                                       "median_abs": float(np.median(dmax)), "radii_equal": bool(np.array_equal(fw[3].cpu().numpy(), ref_maps[2]))}
+            del ref_maps
         if args.workload == "s3":
             # SURVEY.md 8(d) asks for the CPU restatement on S1 and S2: both whole, in the same run, next to the sample
             # of the headline's own workload
@@ -657,7 +674,8 @@ def main():
             for wl in ("s1", "s2"):
                 sc2, cams2, _d, _dc, (P2, W2, H2, D2) = build_scene(wl, torch.device("cpu"))
                 b = _cpu_baseline_once(sc2, cams2[0], P2, W2, H2, D2, P2)
-                b.pop("seconds")
+                for k_ in ("seconds", "_maps", "_n"):
+                    b.pop(k_)
                 others[wl] = b
             cpu_baseline["other_workloads"] = others
 
@@ -769,6 +787,9 @@ def run_cpu_baseline(scene, cam, P, W, H, D, target_gaussians=150_000, target_se
         if n2 > 1.5 * target_gaussians:
             first = _cpu_baseline_once(scene, cam, P, W, H, D, n2)
     first.pop("seconds")
+    if first.get("_n") != P:
+        first.pop("_maps", None)   # (a subset was timed: its render is not the scene's)
+    first.pop("_n", None)
     return first
 
 
@@ -786,14 +807,14 @@ def _cpu_baseline_once(scene, cam, P, W, H, D, target_gaussians):
     go = rng.normal(size=(7, H, W)).astype(np.float32)
     o = om.Oracle()
     t0 = time.perf_counter()
-    R, _, _, radii = o.rasterize_gaussians(np.zeros(3, np.float32), scene.means3D[idx], e, scene.opacities[idx],
+    R, color, others, radii = o.rasterize_gaussians(np.zeros(3, np.float32), scene.means3D[idx], e, scene.opacities[idx],
                                            scene.scales[idx], scene.rotations[idx], 1.0, e, cam.world_view_transform,
                                            cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, scene.shs[idx], D,
                                            cam.camera_center)
     o.rasterize_gaussians_backward(gc, go)
     dt = time.perf_counter() - t0
     V = int((radii > 0).sum())
-    return {"seconds": dt, "value": V / dt, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port",
+    return {"seconds": dt, "_n": n, "_maps": (color, others, radii), "value": V / dt, "unit": "Gaussians/s", "cores": os.cpu_count(), "kind": "port",
             "sample": (f"{n} of {P} surfels" + (" (seeded subset)" if n < P else " (the whole scene)") +
                        f", view 0 at {W}x{H}, 1 fwd+bwd, {V} visible, {R} instances, {dt:.2f} s, OpenMP over all host "
                        f"cores (oracle/surfel_oracle.c)")}

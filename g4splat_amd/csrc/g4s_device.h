@@ -308,7 +308,10 @@ struct PairEval {
     bool in3d;  // the 3-D exponent was the smaller one (always, on the affine path)
 };
 constexpr uint32_t REC_AFFINE = 0x80000000u;
-constexpr float AFFINE_TOL = 4e-5f;  // bound on the relative error of alpha that the affine form may add (see splat_affine)
+#ifndef G4S_AFFINE_TOL
+#define G4S_AFFINE_TOL 2e-5f
+#endif
+constexpr float AFFINE_TOL = G4S_AFFINE_TOL;  // bound on the relative error of alpha that the affine form may add (see splat_affine; swept in profiles/r06_affine_tol.txt)
 
 // The nine coefficients of p' (record quads 2..4) and whether the splat qualifies by (a).
 struct SplatAffine {

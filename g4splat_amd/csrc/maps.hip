@@ -447,7 +447,9 @@ __global__ void __launch_bounds__(256) accumulate_rows_kernel(RowSegs segs, AccS
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (r[u] >= 0) {
+                // (unsigned: a received row whose index column lies outside this chunk -- a source that is not sorted, or
+                // that holds a row of another shard -- is dropped instead of being added outside the LDS tile)
+                if ((unsigned)r[u] < (unsigned)rows) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int f = lane + 64 * q;

@@ -146,9 +146,12 @@ class DensifyMixin:
         self.densification_postfix(*self._pick(sel, [self._xyz, self._features_dc, self._features_rest, self._opacity,
                                                      self._scaling, self._rotation]))
 
-    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
         """:583-610: large Gaussians with a large gradient are replaced by N children sampled inside them (in the
-        splat's own plane: the third standard deviation is 0), each 1/(0.8 N) the size."""
+        splat's own plane: the third standard deviation is 0), each 1/(0.8 N) the size.  `generator` (extension): the
+        torch.Generator the children are drawn from (:598 draws from the process-wide one, which is what None does) --
+        under data parallelism every replica passes one seeded from the iteration, parallel.densify_generator, so that
+        all of them draw the same children."""
         P = self._xyz.shape[0]
         padded = torch.zeros((P,), device=self._xyz.device)
         padded[:grads.shape[0]] = grads.squeeze(-1) if grads.ndim > 1 else grads
@@ -157,7 +160,7 @@ class DensifyMixin:
                                                                      self._features_dc, self._features_rest, self._opacity])
         s = p_scal.repeat(N, 1)
         stds = torch.cat([s, torch.zeros_like(s[:, :1])], dim=-1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
         R = build_rotation(p_rot).repeat(N, 1, 1)
         new_xyz = torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + p_xyz.repeat(N, 1)
         new_scaling = torch.log(s / (0.8 * N))
@@ -166,15 +169,16 @@ class DensifyMixin:
         gone = torch.cat((sel, torch.zeros(N * int(p_xyz.shape[0]), dtype=torch.bool, device=sel.device)))
         self.prune_points(gone)
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
-        """:628-647.  The mip filter is switched off while sizes and opacities are compared, like the reference."""
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """:628-647.  The mip filter is switched off while sizes and opacities are compared, like the reference.
+        `generator`: see densify_and_split."""
         mip = self.use_mip_filter
         self.use_mip_filter = False
         try:
             grads = self.xyz_gradient_accum / self.denom
             grads[grads.isnan()] = 0.0
             self.densify_and_clone(grads, max_grad, extent)
-            self.densify_and_split(grads, max_grad, extent)
+            self.densify_and_split(grads, max_grad, extent, generator=generator)
             prune = (self.get_opacity < min_opacity).squeeze(-1)
             if max_screen_size:
                 prune = prune | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)

@@ -45,16 +45,40 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0)
 
 
-class _Scratch:
-    """resizeFunctional (rasterize_points.cu:31-37) as a C callback."""
+# Size-stable scratch.  The binning chunk and the backward's workspace grow with the frame's instance count, which differs
+# from view to view; torch's caching allocator serves a request from a cached block of the SAME size class at once, but a
+# stream of ever-different sizes splits and re-merges its blocks and re-enters hipMalloc every few steps (7 times in a
+# 60-step pass over eight views at the metric size: the only in-step jitter the bench line still showed).  So every chunk
+# is requested at the largest size this (device, P, width, height) has needed so far: after one pass over the views each
+# call asks for exactly what the previous call freed.  The tensors stay per call, like the reference's (two forwards may
+# be alive at once); only their SIZE is remembered.  Cost: the memory of the largest view instead of the current one.
+_HIGH_WATER = {}
+_SIZE_QUANTUM = 2 << 20  # the allocator's own granularity for large blocks
 
-    def __init__(self, device):
+
+def _stable_size(key, nbytes):
+    nbytes = int(nbytes)
+    if nbytes <= 0 or key is None:
+        return nbytes
+    q = (nbytes + _SIZE_QUANTUM - 1) // _SIZE_QUANTUM * _SIZE_QUANTUM
+    hw = _HIGH_WATER.get(key, 0)
+    if q > hw:
+        if len(_HIGH_WATER) > 4096:  # (a long densification schedule: every P is a new key)
+            _HIGH_WATER.clear()
+        _HIGH_WATER[key] = hw = q
+    return hw
+
+
+class _Scratch:
+    """resizeFunctional (rasterize_points.cu:31-37) as a C callback.  `key`: see _stable_size."""
+
+    def __init__(self, device, key=None):
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
         self.error = None
 
         def _resize(_ctx, nbytes):
             try:
-                self.tensor.resize_(int(nbytes))
+                self.tensor.resize_(_stable_size(key, nbytes))
                 return self.tensor.data_ptr() if nbytes else 1  # non-NULL sentinel for empty chunks
             except Exception as ex:  # surfaced after the C call returns G4S_ERR_ALLOC
                 self.error = ex
@@ -115,7 +139,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     dev = means3D.device
     with torch.cuda.device(dev):
         fopt = dict(dtype=torch.float32, device=dev)
-        geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
+        key = (dev.index, P, W, H)
+        geom, binning, img = _Scratch(dev, key + ("geom",)), _Scratch(dev, key + ("binning",)), _Scratch(dev, key + ("img",))
         if P == 0:  # rasterize_points.cu:85-99: zero-filled outputs, nothing launched
             return (0, torch.zeros((NUM_CHANNELS, H, W), **fopt), torch.zeros((7, H, W), **fopt),
                     torch.zeros((0,), dtype=torch.int32, device=dev), geom.tensor, binning.tensor, img.tensor)
@@ -337,7 +362,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         if P != 0:
             ws_bytes = lib.g4s_rasterizer_backward_workspace(P, int(R))
             if workspace is None:
-                workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                workspace = torch.empty(_stable_size((dev.index, P, W, H, "bwd"), ws_bytes), dtype=torch.uint8, device=dev)
             elif (workspace.dtype != torch.uint8 or workspace.device != dev or not workspace.is_contiguous()
                   or workspace.numel() < ws_bytes):
                 raise RuntimeError(f"out['workspace'] must be a contiguous uint8 tensor of >= {ws_bytes} bytes on {dev}")

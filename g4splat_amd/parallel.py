@@ -478,6 +478,14 @@ class OwnerReduce:
                 # contribution already sits in my slice of the row tensors.
                 if getattr(self, "_packed_all", None) is None:
                     raise RuntimeError("OwnerReduce.finish(prepacked=True) without prepack()")
+                if getattr(self, "debug_checks", False) and total:
+                    # the rows were laid out by the backward from prepack()'s mask, the splits come from begin()'s: the
+                    # index column the backward wrote has to be begin()'s index list, row for row
+                    col = self._packed_all[:total, W].contiguous().view(torch.int32).to(torch.int64)
+                    if not torch.equal(col, self._idx[:total]):
+                        raise RuntimeError("OwnerReduce.finish(prepacked=True): the rows in prepack()'s buffer are not the rows "
+                                           "begin() counted (different `visible` masks, or the backward did not run with "
+                                           "out['packed'])")
                 send[self.rank] = recv[self.rank] = b - a
                 m = sum(recv)
                 in_rows = self._buffer("_recv", m)[:m]
@@ -792,7 +800,7 @@ class ViewParallel:
             self._visible.logical_or_(visibility_filter)
 
     def accumulate(self, views, view_step, in_flight: int = 2, instance_capacity: Optional[int] = None,
-                   check_overflow: bool = True):
+                   check_overflow: bool = True, on_discard=None):
         """This rank's views of one optimisation step, accumulated locally (8 views over N < 8 GPUs).
 
             vp.accumulate(shard_views(batch, rank, world), view_step)     # then vp.all_reduce(); optimizer.step(); vp.zero()
@@ -815,7 +823,16 @@ class ViewParallel:
         sums (zero()), grows the capacity to 1.5 x the count it has just seen, and redoes the step sequentially; the
         next step rebuilds the pipeline at the new size (`regrown` counts these steps).  That presumes the step's
         accumulation started in this call: if something was accumulated since zero() before it, there is nothing safe
-        to discard and the overflow raises."""
+        to discard and the overflow raises.
+
+        CONTRACT for `view_step`: apart from the gradients it adds to this object's bucket it must be free of
+        side effects that a second run would double -- the redo calls it again for EVERY view of the step.  What this method
+        can undo itself it does: the bucket and the statistics are zeroed, and torch's random state (host generator and
+        this device's) is put back to where the discarded pass started, so random backgrounds are drawn again as they
+        were.  What it cannot see -- `.grad` of leaves outside the bucket (exposure / appearance modules), iteration
+        counters, logged losses, hooks that fired on the truncated views' gradients -- is the caller's: `on_discard()` is
+        called after the step's sums were dropped and before the redo, and the method returns {"regrown": True} for such a
+        step ({"regrown": False} otherwise)."""
         views = list(views)
         params = self.bucket.params
         dev = params[0].device
@@ -833,7 +850,7 @@ class ViewParallel:
         sizes = {(int(v.image_width), int(v.image_height)) for v in views}
         if len(views) <= 1 or in_flight <= 1 or dev.type != "cuda" or len(sizes) != 1:
             plain()
-            return
+            return {"regrown": False}
         from .pipeline import ViewPipeline
         (W, H), = sizes
         key = (int(params[0].shape[0]), W, H, min(int(in_flight), len(views)))
@@ -848,10 +865,10 @@ class ViewParallel:
                 seen = plain()
                 # (0: view_step does not run this package's rasterizer front-end on this thread -- nothing to size by)
                 self._capacity[key[:3]] = int(seen * 1.5) + 4096 if seen > 0 else 0
-                return
+                return {"regrown": False}
             if cap == 0:
                 plain()
-                return
+                return {"regrown": False}
             self._pipe = ViewPipeline(key[0], W, H, int(cap), dev, k=key[3])
             self._pipe.order_accumulation(params)
             self._pipe_key = key
@@ -860,8 +877,10 @@ class ViewParallel:
             except AttributeError:
                 pass
         pipe = self._pipe
+        rng = None
         if check_overflow:
             pipe.reset_peak()
+            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(dev))  # (host-side copies of the generator states: no device sync)
         for j, v in enumerate(views):
             with pipe.slot(j):
                 out = view_step(v)
@@ -881,15 +900,19 @@ class ViewParallel:
                 pipe.release_hooks()
                 self._pipe = self._pipe_key = None
                 self.regrown += 1
+                torch.set_rng_state(rng[0])
+                torch.cuda.set_rng_state(rng[1], dev)
+                if on_discard is not None:
+                    on_discard()
                 plain()
+                return {"regrown": True}
+        return {"regrown": False}
 
     def all_reduce(self):
         """Sum the gradient bucket (and the statistics) over all ranks.  Returns the reduced statistics."""
         if dist.is_initialized() and self.world_size > 1 and self.exchange == "owner":
             P = self.bucket.params[0].shape[0]
-            if self._owner is None:
-                self._side = torch.zeros((P, 2), device=self.bucket.flat.device)
-                self._owner = OwnerReduce([v.view(P, -1) for v in self.bucket.views] + [self._side], self.group)
+            self._ensure_owner()
             self._side[:, 0:1] = self.grad_norm_sum
             self._side[:, 1:2] = self.vis_count
             vis = self._visible if self._visible is not None else torch.zeros(P, dtype=torch.bool, device=self._side.device)
@@ -914,6 +937,61 @@ class ViewParallel:
             self.grad_norm_sum, self.vis_count = self._side[:, 0:1].clone(), self._side[:, 1:2].clone()
         return {"grad_norm_sum": self.grad_norm_sum, "vis_count": self.vis_count, "max_radii": self.max_radii}
 
+    # ---- owner-applied optimiser (ZeRO-1) behind the same object ----------------------------------------------------
+    def _ensure_owner(self):
+        if self._owner is None:
+            P = self.bucket.params[0].shape[0]
+            self._side = torch.zeros((P, 2), device=self.bucket.flat.device)
+            self._owner = OwnerReduce([v.view(P, -1) for v in self.bucket.views] + [self._side], self.group)
+        return self._owner
+
+    def sharded_adam(self, lrs, betas=(0.9, 0.999), eps=1e-15):
+        """-> ShardedAdam over this object's parameters, gradient bucket and owner exchange (exchange="owner")."""
+        if self.exchange != "owner":
+            raise RuntimeError("ViewParallel.sharded_adam() needs exchange='owner'")
+        return ShardedAdam([p.data for p in self.bucket.params], self.bucket.views, self._ensure_owner(), lrs, betas=betas, eps=eps)
+
+    def reduce_to_owners(self):
+        """First half of a ZeRO-1 step: the owner exchange up to the owners' accumulation (no gather).  Follow with
+        `opt.step(extra=[vp.side])` -- the updated parameters and the reduced statistics are gathered together -- and
+        `vp.stats_after_owner_step()`."""
+        if self.exchange != "owner" or not dist.is_initialized():
+            raise RuntimeError("ViewParallel.reduce_to_owners() needs exchange='owner' and an initialised process group")
+        own = self._ensure_owner()
+        P = self.bucket.params[0].shape[0]
+        self._side[:, 0:1] = self.grad_norm_sum
+        self._side[:, 1:2] = self.vis_count
+        vis = self._visible if self._visible is not None else torch.zeros(P, dtype=torch.bool, device=self._side.device)
+        own.begin(vis, radii=self.max_radii.to(torch.int32))
+        own.finish(gather=False)
+
+    @property
+    def side(self):
+        """[P, 2] (sum of the per-view gradient norms | visibility count): travels with the gradient rows."""
+        self._ensure_owner()
+        return self._side
+
+    def stats_after_owner_step(self):
+        self.max_radii = self._owner.max_radii.to(self.max_radii.dtype)
+        self.grad_norm_sum, self.vis_count = self._side[:, 0:1].clone(), self._side[:, 1:2].clone()
+        return {"grad_norm_sum": self.grad_norm_sum, "vis_count": self.vis_count, "max_radii": self.max_radii}
+
+    def rebind(self, params):
+        """After a densification the parameters are NEW tensors of another length: a new gradient bucket, statistics of the
+        new length, and everything sized by P (the exchange's persistent buffers, the view pipeline) dropped -- the next
+        step rebuilds them."""
+        if self._pipe is not None:
+            self._pipe.release_hooks()
+        self._pipe = self._pipe_key = None
+        self._owner = self._reducer = self._side = None
+        self.bucket = GradientBucket(params)
+        n, dev = self.bucket.params[0].shape[0], self.bucket.flat.device
+        self.grad_norm_sum = torch.zeros((n, 1), device=dev)
+        self.vis_count = torch.zeros((n, 1), device=dev)
+        self.max_radii = torch.zeros((n,), device=dev)
+        self._visible = None
+        self._dirty = False
+
     def zero(self):
         self.bucket.zero()
         self.grad_norm_sum.zero_()
@@ -921,6 +999,80 @@ class ViewParallel:
         self.max_radii.zero_()
         self._visible = None
         self._dirty = False
+
+
+def densify_generator(device, iteration: int, base_seed: int = 0) -> torch.Generator:
+    """The generator every replica hands to densify_and_prune at `iteration` (gaussian_model.py:598: densify_and_split
+    draws its children with torch.normal): seeded from (base_seed, iteration) alone, so all ranks -- and the single-process
+    run with the same seed -- draw the same numbers without a broadcast."""
+    g = torch.Generator(device=device)
+    g.manual_seed((int(base_seed) * 1_000_003 + int(iteration)) & 0x7FFFFFFFFFFFFFFF)
+    return g
+
+
+class ReplicatedDensification:
+    """`densify_and_prune` under data parallelism: every replica edits its rows itself and all of them end up with the same
+    bits ("identical parameters after densify_and_split"; 2dgs/scene/gaussian_model.py:586-647 driven as in
+    train_with_refine_depth.py:583-593).
+
+    Everything the edit reads is replicated when it runs: the parameters (same bits after every exchange), the
+    densification statistics (accumulated HERE from the REDUCED per-view sums, add_stats()), the Adam moments (replicated
+    optimiser: as they are; ShardedAdam: all-gathered for the edit and re-sharded for the new P).  The one input that is
+    not a function of those is densify_and_split's torch.normal: every rank draws from densify_generator(iteration) -- no
+    communication (a broadcast of the edited rows would move 232 B per Gaussian over one root's links).  After the edit a
+    digest of the new parameters is compared across the ranks (one MIN + one MAX all-reduce of three words) and a
+    divergence raises instead of training on.
+
+        dz = ReplicatedDensification(model, vp, sharded=opt)          # sharded=None: model.optimizer is the replicated Adam
+        ... per step:  stats = vp.all_reduce()  |  vp.reduce_to_owners(); opt.step(extra=[vp.side]); stats = vp.stats_after_owner_step()
+                       dz.add_stats(stats); vp.zero()
+        ... every densification_interval:  dz.densify_and_prune(iteration, max_grad, min_opacity, extent, size_threshold)
+    """
+
+    def __init__(self, model, vp: "ViewParallel", sharded: Optional[ShardedAdam] = None, base_seed: int = 0, check: bool = True):
+        self.model, self.vp, self.sharded, self.base_seed, self.check = model, vp, sharded, int(base_seed), check
+
+    @torch.no_grad()
+    def add_stats(self, stats):
+        """train_with_refine_depth.py:583-584 for the step's views at once: the per-view norms and counts were summed and
+        the radii MAX-reduced by the exchange, identically on every rank."""
+        m = self.model
+        m.xyz_gradient_accum += stats["grad_norm_sum"]
+        m.denom += stats["vis_count"]
+        m.max_radii2D = torch.maximum(m.max_radii2D, stats["max_radii"].to(m.max_radii2D.dtype))
+
+    def _digest(self):
+        ps = self.model.parameters()
+        dev = ps[0].device
+        # (integer sums of the bit patterns: exact, order independent)
+        words = [p.detach().contiguous().view(torch.int32).to(torch.int64).sum() for p in ps]
+        return torch.stack([torch.tensor(ps[0].shape[0], dtype=torch.int64, device=dev), sum(words[:3]), sum(words[3:])])
+
+    @torch.no_grad()
+    def densify_and_prune(self, iteration, max_grad, min_opacity, extent, max_screen_size):
+        m, opt = self.model, self.sharded
+        if opt is not None:
+            # moments live on their owners: gather them, let the row edits carry them as the model optimiser's state
+            ea, es = opt.full_state()
+            for p, a, b in zip(m.parameters(), ea, es):
+                m.optimizer.state[p] = {"step": torch.tensor(float(opt.steps)), "exp_avg": a, "exp_avg_sq": b}
+        m.densify_and_prune(max_grad, min_opacity, extent, max_screen_size,
+                            generator=densify_generator(m._xyz.device, iteration, self.base_seed))
+        params = m.parameters()
+        self.vp.rebind(params)
+        if opt is not None:
+            st = [m.optimizer.state.pop(p) for p in params]
+            opt.load_full_state([p.data for p in params], self.vp.bucket.views, self.vp._ensure_owner(),
+                                [s_["exp_avg"] for s_ in st], [s_["exp_avg_sq"] for s_ in st])
+        if self.check and dist.is_initialized() and self.vp.world_size > 1:
+            d = self._digest()
+            lo, hi = d.clone(), d.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.vp.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.vp.group)
+            if not torch.equal(lo, hi):
+                raise RuntimeError(f"ReplicatedDensification: the replicas differ after densify_and_prune at iteration "
+                                   f"{iteration} (rows / digests min {lo.tolist()} max {hi.tolist()})")
+        return params
 
 
 def broadcast_parameters(params: Iterable[torch.Tensor], src: int = 0, group: Optional[dist.ProcessGroup] = None):

@@ -126,11 +126,11 @@ def rel_err(a, b):
 # tools/parity_report.py, profiles/r02_parity_report.txt): they are what the tests assert, so that a regression
 # of one order of magnitude is caught long before the contract is at risk.
 #
-# (max_flipped_frac = 4e-5 of the frame: about twice what S2 / S3 / S5 show since round 5 -- 5e-6 / 1.8e-5 / 2e-5.  Until
-# round 4 the HIP path shared the oracle's arithmetic up to one v_rcp_f32 and one v_exp_f32 per pair (~3e-7 relative in
-# alpha) and flipped 9e-6 of S3's pixels; the affine ray-splat intersection of round 5 (csrc/g4s_device.h) is a different,
-# equally accurate single-precision evaluation of the same quantity, ~1e-6 relative from the oracle's, and flips twice as
-# many of the pixels that sit within MARGIN of a threshold.)
+# (max_flipped_frac: until round 4 the HIP path shared the oracle's arithmetic up to one v_rcp_f32 and one v_exp_f32 per pair
+# (~3e-7 relative in alpha) and flipped 9e-6 of S3's pixels -- that gate, cap 2e-5, still holds for option `no_fastpath`
+# (STRICT below).  The affine ray-splat intersection of round 5 (csrc/g4s_device.h) is a different, equally accurate
+# single-precision evaluation of the same quantity, ~1e-6 relative from the oracle's, and flips twice as many of the
+# pixels that sit on a threshold: 1.2e-5 .. 1.8e-5 of S3's frames (profiles/r06_affine_tol.txt), cap 4e-5.)
 # A pixel or gradient row outside a bar is accepted ONLY if it is *explained*: the oracle reports, per pixel,
 # how close each discrete decision of the forward loop (alpha >= 1/255, depth >= near, T(1-alpha) >= 1e-4,
 # T > 0.5) came to its threshold (oracle.pixel_margins).  Any two correct single-precision evaluations differ
@@ -141,8 +141,12 @@ OUT_ATOL_GUARD = 2e-5    # guard: measured <= 2.9e-6 on S1..S5 and 60 fuzz scene
 GRAD_RTOL_GUARD = 1e-4   # guard: measured <= 1.1e-5 tensor-level (typically 1e-6)
 ROW_RTOL_GUARD = 1e-2    # guard, row-level (measured <= 8.6e-4): |a-b|_row,inf / |b|_row,inf for rows above ROW_FLOOR of the tensor's max
 ROW_FLOOR = 1e-3
-MARGIN = 4e-5            # relative distance to a decision threshold below which either side is correct: the bound the
-                         # REC_AFFINE certificate puts on the affine form's alpha (AFFINE_TOL, csrc/g4s_device.h); 1e-5 until round 4
+MARGIN = 1e-5            # relative distance to a decision threshold below which either side is correct.  Round 4's value
+                         # again (round 5 had tied it to AFFINE_TOL = 4e-5): the sweep of profiles/r06_affine_tol.txt shows every
+                         # flipped pixel of S1 / S3 / S3t within 1e-5 of its threshold whatever AFFINE_TOL (1e-5, 2e-5, 4e-5) --
+                         # the gate is independent of the certificate's own bound (now 2e-5) again
+CONTRACT_PIXELS_FRAC = 4e-5   # pixels that may lie beyond the contract's 1e-4 abs against the oracle (threshold flips), of the frame
+STRICT = dict(max_flipped_frac=2e-5, exempt_skip_suspects=False)   # round 4's gate, for runs on the reference's arithmetic
 
 
 def _last_and_median_ids(n_contrib, ranges, ids, W, H):
@@ -158,7 +162,7 @@ def _last_and_median_ids(n_contrib, ranges, ids, W, H):
     return out
 
 
-def parity_report(h, o, inp, oracle_mod, scale_aware=False, masked_rerun=True):
+def parity_report(h, o, inp, oracle_mod, scale_aware=False, masked_rerun=True, exempt_skip_suspects=True):
     """Compares a HIP result `h` (run_hip) with the oracle's `o` (run_oracle) and classifies every mismatch.
     Returns a dict of measured errors (over the unexplained part) and of the explained sets.
     scale_aware: output errors of a map are taken relative to max(1, max |map|) -- for scenes blown up on purpose
@@ -179,6 +183,9 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False, masked_rerun=True):
     rep["out_err_unexplained"] = float(dmax[~suspect].max()) if (~suspect).any() else 0.0
     rep["out_err_per_map_unexplained"] = [float(d[~suspect].max()) if (~suspect).any() else 0.0 for d in diffs]
     rep["out_err_all"] = float(dmax.max()) if N else 0.0
+    # the contract read literally (north_star: "outputs <= 1e-4 abs"): how many pixels lie beyond it, and the worst of them
+    rep["pixels_beyond_contract"] = int((dmax > OUT_ATOL).sum())
+    rep["worst_abs"] = rep["out_err_all"]
     # ---- contributor bookkeeping, as Gaussian ids
     st = hip_state(h, inp) if o["R"] > 0 else None
     if st is not None:
@@ -222,7 +229,9 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False, masked_rerun=True):
         # weight ~T/255 at that pixel: mostly invisible in the outputs (so the pixel is not among the `flipped` ones), but it
         # is that pixel's whole contribution to that Gaussian's gradient rows -- several per cent of a row that only a few
         # pixels feed.  Those Gaussians are explained too, and their pixels join the masked comparison below.
-        explained[sk_gid] = True
+        # (exempt_skip_suspects=False -- round 4's gate, for runs on the reference's arithmetic: neither exempt nor masked)
+        if exempt_skip_suspects:
+            explained[sk_gid] = True
         rep["skip_suspect_pairs"] = int(len(sk_pix))
         if flipped.any():
             tiles_x = (W + 15) // 16
@@ -257,7 +266,8 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False, masked_rerun=True):
         # bars: what remains unchecked is exactly the contribution of the (capped number of) flipped pixels themselves.
         rep["grads_masked"] = None
         masked = flipped.copy()
-        masked[sk_pix] = True
+        if exempt_skip_suspects:
+            masked[sk_pix] = True
         rep["masked_pixels"] = int(masked.sum())
         if masked_rerun and masked.any() and "cot" in h and "cot" in o:
             gc = np.array(h["cot"][0], np.float32, copy=True).reshape(3, N)
@@ -285,13 +295,21 @@ def parity_report(h, o, inp, oracle_mod, scale_aware=False, masked_rerun=True):
 
 
 def assert_parity(h, o, inp, oracle_mod, tag="", out_atol=OUT_ATOL_GUARD, grad_rtol=GRAD_RTOL_GUARD,
-                  row_rtol=ROW_RTOL_GUARD, max_flipped_frac=4e-5, scale_aware=False, masked_rerun=True):
+                  row_rtol=ROW_RTOL_GUARD, max_flipped_frac=4e-5, scale_aware=False, masked_rerun=True,
+                  exempt_skip_suspects=True):
     """The parity gate of the GPU tests: exact integers, guard bars on everything that is not explained by a
-    decision threshold, and a cap on how much may be explained away."""
+    decision threshold, and a cap on how much may be explained away.  `**STRICT` = round 4's gate (flip cap 2e-5 of the
+    frame, Gaussians with a near-threshold skip decision neither exempt nor masked), which runs on the reference's
+    arithmetic (option no_fastpath) still have to meet."""
     assert h["R"] == o["R"], tag
     np.testing.assert_array_equal(h["radii"], o["radii"], err_msg=tag)
-    rep = parity_report(h, o, inp, oracle_mod, scale_aware=scale_aware, masked_rerun=masked_rerun)
+    rep = parity_report(h, o, inp, oracle_mod, scale_aware=scale_aware, masked_rerun=masked_rerun,
+                        exempt_skip_suspects=exempt_skip_suspects)
     N = rep["N"]
+    if not scale_aware:
+        # (the same allowance as for the flips below: every one of these pixels has to be a matched flip anyway)
+        assert rep["pixels_beyond_contract"] <= max(2, CONTRACT_PIXELS_FRAC * N, 0.02 * rep["suspect_pixels"]), \
+            (tag, "pixels beyond 1e-4 abs", rep)
     assert rep["out_err_unexplained"] <= out_atol, (tag, "output beyond the bar on a pixel that is on no threshold", rep)
     assert rep["id_mismatch_unexplained"] == 0, (tag, "contributor mismatch on a pixel that is on no threshold", rep)
     # how many pixels may flip: a share of the frame -- or, where the lists are so deep that a frame has thousands of

@@ -478,3 +478,151 @@ def test_owner_exchange_at_the_metric_row_counts_on_eight_ranks(P):
             assert nbytes["all_to_all_sent"] == sent * 61 * 4
     assert res[world - 1][1][4] == 0                              # the rank that saw nothing sent nothing
     assert res[0][0][5]["all_gather_received"] > 300e6            # ~315 MB in, as DESIGN.md section 5 prices it
+
+
+# ---- densification under data parallelism ("identical parameters after densify_and_split") ----------------
+DENSIFY_STEPS = 3          # optimiser steps before and after the densification
+DENSIFY_ARGS = dict(max_grad=None, min_opacity=0.005, extent=12.0, max_screen_size=None)  # max_grad: set from the scene below
+
+
+def _densify_model():
+    m = _model(seed=0)
+    with torch.no_grad():
+        m._opacity[::7] -= 6.0        # translucent rows: pruned (opacity < 0.005)
+    m.training_setup()
+    return m
+
+
+def _densify_pack(model, exp_avg, exp_avg_sq, history):
+    c = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).numpy()
+    return dict(params=c(model.parameters()), exp_avg=c(exp_avg), exp_avg_sq=c(exp_avg_sq),
+                accum=model.xyz_gradient_accum.numpy().copy(), denom=model.denom.numpy().copy(),
+                radii=model.max_radii2D.numpy().copy(), history=history)
+
+
+def _densify_dp_worker(rank, world, port, q, zero1=True):
+    """k steps through ViewParallel (+ ShardedAdam when `zero1`, else the model's own replicated Adam behind a gathered
+    exchange), ONE densify_and_prune on every replica, k more steps."""
+    os.environ["OMP_NUM_THREADS"] = "1"   # the checker's backward sums with OpenMP atomics: one thread = one summation order
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from g4splat_amd.parallel import ReplicatedDensification, ViewParallel, shard_views
+    model = _densify_model()
+    vp = ViewParallel(model.parameters(), exchange="owner")
+    lrs = [g["lr"] for g in model.optimizer.param_groups]
+    opt = vp.sharded_adam(lrs) if zero1 else None
+    dz = ReplicatedDensification(model, vp, sharded=opt, base_seed=5)
+    views = _views(2)
+    history = []
+    for it in range(1, 2 * DENSIFY_STEPS + 1):
+        _step(model, shard_views(views, rank, world), vp)
+        if zero1:
+            vp.reduce_to_owners()
+            opt.step(extra=[vp.side])
+            dz.add_stats(vp.stats_after_owner_step())
+        else:
+            dz.add_stats(vp.all_reduce())
+            model.optimizer.step()
+        vp.zero()
+        if it == DENSIFY_STEPS:
+            before = model._xyz.shape[0]
+            grads = (model.xyz_gradient_accum / model.denom).nan_to_num(0.0)
+            args = dict(DENSIFY_ARGS, max_grad=float(grads[grads > 0].median()))
+            dz.densify_and_prune(it, **args)
+            history.append((before, model._xyz.shape[0]))
+            if zero1:
+                assert opt.exp_avg[0].shape[0] == opt.red.bounds()[1] - opt.red.bounds()[0]  # state exists for the shard only
+    if zero1:
+        ea, es = opt.full_state()
+    else:
+        st = [model.optimizer.state[p] for p in model.parameters()]
+        ea, es = [x["exp_avg"] for x in st], [x["exp_avg_sq"] for x in st]
+    q.put((rank, _densify_pack(model, ea, es, history)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _densify_single_process():
+    """The same schedule in ONE process without any exchange machinery: both views accumulated into one bucket, plain Adam
+    over the full tensors, the statistics taken per view, densify_and_prune with the generator of the iteration."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    _setup_paths()
+    from g4splat_amd.parallel import ViewParallel, adam_update_, densify_generator
+    model = _densify_model()
+    vp = ViewParallel(model.parameters())            # no process group: a gradient bucket and the per-view statistics
+    lrs = [g["lr"] for g in model.optimizer.param_groups]
+    m1 = [torch.zeros_like(p) for p in model.parameters()]
+    m2 = [torch.zeros_like(p) for p in model.parameters()]
+    views = _views(2)
+    history, steps = [], 0
+    for it in range(1, 2 * DENSIFY_STEPS + 1):
+        _step(model, views, vp)
+        steps += 1
+        with torch.no_grad():
+            for p, a, b, lr in zip(model.parameters(), m1, m2, lrs):
+                adam_update_(p.data, p.grad, a, b, lr, steps, eps=1e-15)
+            model.xyz_gradient_accum += vp.grad_norm_sum
+            model.denom += vp.vis_count
+            model.max_radii2D = torch.maximum(model.max_radii2D, vp.max_radii)
+        vp.zero()
+        if it == DENSIFY_STEPS:
+            before = model._xyz.shape[0]
+            grads = (model.xyz_gradient_accum / model.denom).nan_to_num(0.0)
+            args = dict(DENSIFY_ARGS, max_grad=float(grads[grads > 0].median()))
+            for p, a, b in zip(model.parameters(), m1, m2):
+                model.optimizer.state[p] = {"step": torch.tensor(float(steps)), "exp_avg": a, "exp_avg_sq": b}
+            with torch.no_grad():
+                model.densify_and_prune(generator=densify_generator("cpu", it, 5), **args)
+            st = [model.optimizer.state.pop(p) for p in model.parameters()]
+            m1, m2 = [s["exp_avg"] for s in st], [s["exp_avg_sq"] for s in st]
+            vp.rebind(model.parameters())
+            history.append((before, model._xyz.shape[0]))
+    return _densify_pack(model, m1, m2, history)
+
+
+def _densify_single_worker(q):
+    q.put(_densify_single_process())
+
+
+@pytest.mark.parametrize("zero1", [True, False])
+def test_densify_and_prune_under_data_parallelism_matches_the_single_process_run(zero1):
+    """Verdict r5 item 3: world 2, one view per rank per step, owner exchange + ZeRO-1; after three steps every replica runs
+    densify_and_prune itself (clone + split + prune; the split's children drawn from the iteration's generator), re-shards
+    the moments for the new row count, and trains on.  Parameters, Adam moments and densification statistics are THE SAME
+    BITS on both ranks and in the single-process run of the same schedule (two views accumulated, full-tensor Adam, no
+    exchange code at all).  Reference behaviour: gaussian_model.py:586-647, train_with_refine_depth.py:583-593.
+    zero1=False: the same through the gathered exchange and the model's own (replicated) torch.optim.Adam -- the replicas
+    hold the same bits and made the same edit; against the single-process run (whose Adam is this repository's plain
+    formula, not torch's kernel) the parameters agree to rounding."""
+    _setup_paths()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    port = 41500 + (os.getpid() % 2000) + (17 if zero1 else 0)
+    procs = [ctx.Process(target=_densify_dp_worker, args=(r, world, port, q, zero1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    single = ctx.Process(target=_densify_single_worker, args=(q1,))   # (its own process: OMP_NUM_THREADS has to be set before the checker loads)
+    single.start()
+    ref = q1.get(timeout=600)
+    single.join(timeout=60)
+    (before, after), = ref["history"]
+    assert before == 150 and after != before
+    for r in range(world):
+        assert res[r]["history"] == ref["history"], (r, res[r]["history"], ref["history"])
+        for key in ("params", "exp_avg", "exp_avg_sq", "accum", "denom", "radii"):
+            np.testing.assert_array_equal(res[r][key], res[0][key], err_msg=f"rank {r} vs rank 0: {key}")
+            if zero1:
+                np.testing.assert_array_equal(res[r][key], ref[key], err_msg=f"rank {r}: {key}")
+            else:
+                np.testing.assert_allclose(res[r][key], ref[key], rtol=2e-4, atol=1e-6, err_msg=f"rank {r}: {key}")
+    # the edit did all three things: rows were cloned and split (more rows than kept ones) and pruned
+    assert after > before - (before + 6) // 7
