@@ -70,21 +70,34 @@ def _stable_size(key, nbytes):
 
 
 class _Scratch:
-    """resizeFunctional (rasterize_points.cu:31-37) as a C callback.  `key`: see _stable_size."""
+    """resizeFunctional (rasterize_points.cu:31-37) as a C callback.  `key`: see _stable_size.
+
+    The callback closes over a plain dict, NOT over this object: `self -> cb -> closure -> self` would be a reference cycle,
+    and the chunk tensor inside it would live until CPython's cyclic collector next runs instead of dying with the last
+    reference -- 388 MiB per forward at the metric size piling up for a dozen steps, which is what made torch's allocator
+    re-enter hipMalloc inside the timed region (tools/alloc_debug.py, profiles/r06_allocations.txt)."""
 
     def __init__(self, device, key=None):
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.error = None
+        state = {"tensor": torch.empty(0, dtype=torch.uint8, device=device), "error": None}
+        self._state = state
 
         def _resize(_ctx, nbytes):
             try:
-                self.tensor.resize_(_stable_size(key, nbytes))
-                return self.tensor.data_ptr() if nbytes else 1  # non-NULL sentinel for empty chunks
+                state["tensor"].resize_(_stable_size(key, nbytes))
+                return state["tensor"].data_ptr() if nbytes else 1  # non-NULL sentinel for empty chunks
             except Exception as ex:  # surfaced after the C call returns G4S_ERR_ALLOC
-                self.error = ex
+                state["error"] = ex
                 return 0
 
         self.cb = _lib.RESIZE_FN(_resize)
+
+    @property
+    def tensor(self):
+        return self._state["tensor"]
+
+    @property
+    def error(self):
+        return self._state["error"]
 
 
 def _check_shapes(P, background, colors, opacity, scales, rotations, transMat_precomp, viewmatrix, projmatrix, sh, campos):

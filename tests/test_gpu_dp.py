@@ -789,14 +789,17 @@ def _dz_view_step(model, cam, target, cfg, bg):
 
 def _dz_densify_args(model):
     grads = (model.xyz_gradient_accum / model.denom).nan_to_num(0.0)
-    extent = float(model.get_scaling.max(dim=1).values.median()) / 0.01   # half of the selected rows clone, half split
+    extent = float(model.get_scaling.detach().max(dim=1).values.median()) / 0.01   # half of the selected rows clone, half split
     return dict(max_grad=float(grads[grads > 0].median()), min_opacity=0.005, extent=extent, max_screen_size=20)
 
 
 def _dz_pack(model, exp_avg, exp_avg_sq, history):
-    c = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).cpu()
-    return dict(params=c(model.parameters()), exp_avg=c(exp_avg), exp_avg_sq=c(exp_avg_sq), accum=model.xyz_gradient_accum.cpu(),
-                denom=model.denom.cpu(), radii=model.max_radii2D.cpu(), history=history)
+    # (numpy, pickled by value: a torch tensor in a multiprocessing queue travels as a shared-memory handle that dies with
+    # the rank that sent it)
+    c = lambda ts: torch.cat([t.detach().reshape(-1) for t in ts]).cpu().numpy()
+    n = lambda t: t.detach().cpu().numpy()
+    return dict(params=c(model.parameters()), exp_avg=c(exp_avg), exp_avg_sq=c(exp_avg_sq), accum=n(model.xyz_gradient_accum),
+                denom=n(model.denom), radii=n(model.max_radii2D), history=history)
 
 
 def _dz_worker(rank, world, port, q):
@@ -881,7 +884,7 @@ def _dz_single_process(world):
     return _dz_pack(model, [x["exp_avg"] for x in st], [x["exp_avg_sq"] for x in st], history)
 
 
-@pytest.mark.parametrize("world", [8, 2])
+@pytest.mark.parametrize("world", [8, pytest.param(2, marks=pytest.mark.exhaustive)])
 def test_densify_and_prune_on_every_replica_with_eight_ranks_on_one_gpu(world):
     """Verdict r5 item 3(b): BASELINE config 4's shape -- eight training views, one per rank -- with the ranks sharing the
     one GPU of the test box (gloo; the device path of the exchange, g4s_adam_step on the owners' shards, the HIP
@@ -889,6 +892,7 @@ def test_densify_and_prune_on_every_replica_with_eight_ranks_on_one_gpu(world):
     densify_and_prune on every replica (clone + split + prune + screen-size limit; the Adam moments gathered for the edit
     and re-sharded for the new row count), three more steps.  Parameters, moments and statistics: the same bits on all
     eight ranks, and the same bits as the single-process run that writes the data-parallel sums out by hand."""
+    import numpy as np
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 43500 + (os.getpid() % 2000) + world
@@ -905,6 +909,6 @@ def test_densify_and_prune_on_every_replica_with_eight_ranks_on_one_gpu(world):
     for r in range(world):
         assert res[r]["history"] == ref["history"], (r, res[r]["history"], ref["history"])
         for key in ("params", "exp_avg", "exp_avg_sq", "accum", "denom", "radii"):
-            assert torch.equal(res[r][key], res[0][key]), f"rank {r} differs from rank 0 in {key}"
-            assert torch.equal(res[r][key], ref[key]), (f"rank {r} differs from the single-process run in {key}",
-                                                        float((res[r][key] - ref[key]).abs().max()))
+            assert np.array_equal(res[r][key], res[0][key]), f"rank {r} differs from rank 0 in {key}"
+            assert np.array_equal(res[r][key], ref[key]), (f"rank {r} differs from the single-process run in {key}",
+                                                           float(np.abs(res[r][key] - ref[key]).max()))

@@ -253,7 +253,7 @@ def test_densification_on_the_gpu_replays_the_reference(hip_lib, monkeypatch):
     z = np.load(os.path.join(gold_dir, "densify.npz"))
     dev = torch.device("cuda:0")
     real_normal = torch.normal
-    monkeypatch.setattr(torch, "normal", lambda mean, std: real_normal(mean=mean.cpu(), std=std.cpu()).to(mean.device))
+    monkeypatch.setattr(torch, "normal", lambda mean, std, generator=None: real_normal(mean=mean.cpu(), std=std.cpu()).to(mean.device))
     t = lambda a: torch.tensor(a, device=dev)
     gm = GaussianModel(3)
     gm.create_from_parameters(t(z["in_means"]), t(z["in_scales"]), t(z["in_quats"]), t(z["in_colors"]), 1.0)

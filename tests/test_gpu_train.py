@@ -303,7 +303,7 @@ def test_config3_densification_at_size_edits_a_material_share_of_the_rows(hip_li
     real_normal = torch.normal
     draws = {}
 
-    def normal_from_cpu(mean, std):  # the GPU's generator differs from the CPU's: both sides take the CPU stream
+    def normal_from_cpu(mean, std, generator=None):  # the GPU's generator differs from the CPU's: both sides take the CPU stream
         key = tuple(std.shape)
         if key not in draws:
             g = torch.Generator().manual_seed(1234)
