@@ -433,10 +433,14 @@ class OwnerReduce:
             issue()
 
     # ---- second half: rows to their owners, owners accumulate, (optionally) everybody gets every shard ------------
-    def finish(self, gather: bool = True, prepacked: bool = False):
+    def finish(self, gather: bool = True, prepacked: bool = False, gather_rows: Optional[Sequence[int]] = None):
         """Reduces the rows in place.  gather=True: on return every row view holds the sum over all ranks.
         gather=False: only this rank's own rows [bounds()) do (what an owner-applied optimiser needs).
         prepacked=True: the backward has already written this rank's visible rows into prepack()'s buffer.
+        gather_rows: indices of the row tensors the gather covers (default: all).  The others stay reduced on their
+        OWNER only -- the densification statistics, which nobody reads between two densifications, are kept that way and
+        gathered once per densification interval instead of once per step (ReplicatedDensification(defer_stats=True)).
+        (When the sparse gather applies -- the union of the visible sets is small -- it moves every row tensor regardless.)
 
         PRECONDITION: a row this rank did not flag `visible` in begin() holds zeros here (what the rasterizer's backward
         leaves: every gradient of a Gaussian with radii == 0 is zero).  Only visible rows travel to their owners, and the
@@ -552,6 +556,14 @@ class OwnerReduce:
                     self._sparse_gather(cu)
                     return
             self.last_gather = "dense"
+            if gather_rows is not None and len(set(gather_rows)) < len(self.rows):
+                sub = [self.rows[i] for i in sorted(set(gather_rows))]
+                Wg = sum(int(r.shape[1]) for r in sub)
+                self.last_bytes["all_gather_sent_per_peer"] = (hi - lo) * Wg * 4
+                self.last_bytes["all_gather_received"] = (self.P - (hi - lo)) * Wg * 4
+                with self._timed("all_gather"):
+                    self.all_gather_rows(sub)   # (ragged shards: per-tensor staging inside)
+                return
             self.last_bytes["all_gather_sent_per_peer"] = (hi - lo) * W * 4
             self.last_bytes["all_gather_received"] = (self.P - (hi - lo)) * W * 4
             if self.even:
@@ -908,8 +920,11 @@ class ViewParallel:
                 return {"regrown": True}
         return {"regrown": False}
 
-    def all_reduce(self):
-        """Sum the gradient bucket (and the statistics) over all ranks.  Returns the reduced statistics."""
+    def all_reduce(self, gather_stats: bool = True):
+        """Sum the gradient bucket (and the statistics) over all ranks.  Returns the reduced statistics.
+        gather_stats=False (owner exchange only): the gradients are gathered, the two statistics columns stay reduced on
+        their owners (`side`, rows bounds()) -- see ReplicatedDensification(defer_stats=True); the returned grad_norm_sum /
+        vis_count are then valid for this rank's own rows only."""
         if dist.is_initialized() and self.world_size > 1 and self.exchange == "owner":
             P = self.bucket.params[0].shape[0]
             self._ensure_owner()
@@ -919,7 +934,7 @@ class ViewParallel:
             # (a training loop that drives OwnerReduce itself calls begin() right after its forward, so that the size
             # exchange hides behind the backward -- bench.py does; here both halves run back to back)
             self._owner.begin(vis, radii=self.max_radii.to(torch.int32))  # the radii MAX rides in the same collective
-            self._owner.finish()
+            self._owner.finish(gather_rows=None if gather_stats else range(len(self.bucket.views)))
             self.max_radii = self._owner.max_radii.to(self.max_radii.dtype)
             self.grad_norm_sum, self.vis_count = self._side[:, 0:1].clone(), self._side[:, 1:2].clone()
         elif dist.is_initialized() and self.world_size > 1:
@@ -1029,8 +1044,17 @@ class ReplicatedDensification:
         ... every densification_interval:  dz.densify_and_prune(iteration, max_grad, min_opacity, extent, size_threshold)
     """
 
-    def __init__(self, model, vp: "ViewParallel", sharded: Optional[ShardedAdam] = None, base_seed: int = 0, check: bool = True):
+    def __init__(self, model, vp: "ViewParallel", sharded: Optional[ShardedAdam] = None, base_seed: int = 0, check: bool = True,
+                 defer_stats: bool = False):
+        """defer_stats=True (owner exchange): the two statistics columns are NOT gathered every step.  Every rank accumulates
+        the reduced per-step sums of ITS OWN rows only (add_owner_stats() after the owners' accumulation; the step is
+        `vp.reduce_to_owners(); opt.step()` or `vp.all_reduce(gather_stats=False)`), and densify_and_prune() starts by
+        all-gathering the accumulated columns once -- 2 of the 60 floats per row leave the per-step gather (-3.3 % of its
+        bytes), the same additions happen in the same order on the row's owner, so the statistics the edit reads are the same
+        bits as with the per-step gather (tests/test_dp_gloo.py)."""
         self.model, self.vp, self.sharded, self.base_seed, self.check = model, vp, sharded, int(base_seed), check
+        self.defer_stats = bool(defer_stats)
+        self._stats_local = False   # defer_stats: the accumulators hold owner-local sums that have not been gathered yet
 
     @torch.no_grad()
     def add_stats(self, stats):
@@ -1040,6 +1064,28 @@ class ReplicatedDensification:
         m.xyz_gradient_accum += stats["grad_norm_sum"]
         m.denom += stats["vis_count"]
         m.max_radii2D = torch.maximum(m.max_radii2D, stats["max_radii"].to(m.max_radii2D.dtype))
+
+    @torch.no_grad()
+    def add_owner_stats(self):
+        """defer_stats: after the owners' accumulation of this step (vp.side holds the reduced sums in this rank's own
+        rows), add them to this rank's rows of the model's accumulators; the radii MAX is replicated by the exchange's
+        first collective as always."""
+        m, own = self.model, self.vp._owner
+        lo, hi = own.bounds()
+        side = self.vp.side
+        m.xyz_gradient_accum[lo:hi] += side[lo:hi, 0:1]
+        m.denom[lo:hi] += side[lo:hi, 1:2]
+        m.max_radii2D = torch.maximum(m.max_radii2D, own.max_radii.to(m.max_radii2D.dtype))
+        self._stats_local = True
+
+    @torch.no_grad()
+    def gather_stats(self):
+        """defer_stats: every rank holds the accumulated statistics of its own rows only; replicate them (one all_gather of
+        two columns, once per densification interval).  densify_and_prune() calls this itself; a caller that derives its
+        thresholds from the statistics calls it first.  Idempotent until the next add_owner_stats()."""
+        if self.defer_stats and self._stats_local and dist.is_initialized() and self.vp.world_size > 1:
+            self.vp._ensure_owner().all_gather_rows([self.model.xyz_gradient_accum, self.model.denom])
+        self._stats_local = False
 
     def _digest(self):
         ps = self.model.parameters()
@@ -1051,6 +1097,7 @@ class ReplicatedDensification:
     @torch.no_grad()
     def densify_and_prune(self, iteration, max_grad, min_opacity, extent, max_screen_size):
         m, opt = self.model, self.sharded
+        self.gather_stats()
         if opt is not None:
             # moments live on their owners: gather them, let the row edits carry them as the model optimiser's state
             ea, es = opt.full_state()

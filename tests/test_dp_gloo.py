@@ -500,7 +500,7 @@ def _densify_pack(model, exp_avg, exp_avg_sq, history):
                 radii=model.max_radii2D.numpy().copy(), history=history)
 
 
-def _densify_dp_worker(rank, world, port, q, zero1=True):
+def _densify_dp_worker(rank, world, port, q, zero1=True, defer=False):
     """k steps through ViewParallel (+ ShardedAdam when `zero1`, else the model's own replicated Adam behind a gathered
     exchange), ONE densify_and_prune on every replica, k more steps."""
     os.environ["OMP_NUM_THREADS"] = "1"   # the checker's backward sums with OpenMP atomics: one thread = one summation order
@@ -514,21 +514,32 @@ def _densify_dp_worker(rank, world, port, q, zero1=True):
     vp = ViewParallel(model.parameters(), exchange="owner")
     lrs = [g["lr"] for g in model.optimizer.param_groups]
     opt = vp.sharded_adam(lrs) if zero1 else None
-    dz = ReplicatedDensification(model, vp, sharded=opt, base_seed=5)
+    dz = ReplicatedDensification(model, vp, sharded=opt, base_seed=5, defer_stats=defer)
     views = _views(2)
     history = []
+    gathered = []
     for it in range(1, 2 * DENSIFY_STEPS + 1):
         _step(model, shard_views(views, rank, world), vp)
         if zero1:
             vp.reduce_to_owners()
-            opt.step(extra=[vp.side])
-            dz.add_stats(vp.stats_after_owner_step())
+            if defer:   # the statistics stay on their owners: only the parameters are gathered
+                opt.step()
+                dz.add_owner_stats()
+            else:
+                opt.step(extra=[vp.side])
+                dz.add_stats(vp.stats_after_owner_step())
+        elif defer:
+            vp.all_reduce(gather_stats=False)
+            dz.add_owner_stats()
+            model.optimizer.step()
         else:
             dz.add_stats(vp.all_reduce())
             model.optimizer.step()
+        gathered.append(vp._owner.last_bytes.get("all_gather_received"))
         vp.zero()
         if it == DENSIFY_STEPS:
             before = model._xyz.shape[0]
+            dz.gather_stats()   # (defer: this test derives its threshold from the statistics, so they are replicated first)
             grads = (model.xyz_gradient_accum / model.denom).nan_to_num(0.0)
             args = dict(DENSIFY_ARGS, max_grad=float(grads[grads > 0].median()))
             dz.densify_and_prune(it, **args)
@@ -540,7 +551,10 @@ def _densify_dp_worker(rank, world, port, q, zero1=True):
     else:
         st = [model.optimizer.state[p] for p in model.parameters()]
         ea, es = [x["exp_avg"] for x in st], [x["exp_avg_sq"] for x in st]
-    q.put((rank, _densify_pack(model, ea, es, history)))
+    dz.gather_stats()  # (defer: the last interval's statistics are still owner-local; replicate them for the comparison)
+    out = _densify_pack(model, ea, es, history)
+    out["gathered"] = gathered
+    q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -587,22 +601,23 @@ def _densify_single_worker(q):
     q.put(_densify_single_process())
 
 
-@pytest.mark.parametrize("zero1", [True, False])
-def test_densify_and_prune_under_data_parallelism_matches_the_single_process_run(zero1):
+@pytest.mark.parametrize("zero1,defer", [(True, False), (False, False), (True, True), (False, True)])
+def test_densify_and_prune_under_data_parallelism_matches_the_single_process_run(zero1, defer):
     """Verdict r5 item 3: world 2, one view per rank per step, owner exchange + ZeRO-1; after three steps every replica runs
     densify_and_prune itself (clone + split + prune; the split's children drawn from the iteration's generator), re-shards
     the moments for the new row count, and trains on.  Parameters, Adam moments and densification statistics are THE SAME
     BITS on both ranks and in the single-process run of the same schedule (two views accumulated, full-tensor Adam, no
     exchange code at all).  Reference behaviour: gaussian_model.py:586-647, train_with_refine_depth.py:583-593.
-    zero1=False: the same through the gathered exchange and the model's own (replicated) torch.optim.Adam -- the replicas
+    defer=True: the statistics columns stay on their owners between densifications (ReplicatedDensification(defer_stats=True))
+    and are gathered once for the edit -- same bits.  zero1=False: the same through the gathered exchange and the model's own (replicated) torch.optim.Adam -- the replicas
     hold the same bits and made the same edit; against the single-process run (whose Adam is this repository's plain
     formula, not torch's kernel) the parameters agree to rounding."""
     _setup_paths()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     world = 2
-    port = 41500 + (os.getpid() % 2000) + (17 if zero1 else 0)
-    procs = [ctx.Process(target=_densify_dp_worker, args=(r, world, port, q, zero1)) for r in range(world)]
+    port = 41500 + (os.getpid() % 2000) + (17 if zero1 else 0) + (31 if defer else 0)
+    procs = [ctx.Process(target=_densify_dp_worker, args=(r, world, port, q, zero1, defer)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))
@@ -624,5 +639,11 @@ def test_densify_and_prune_under_data_parallelism_matches_the_single_process_run
                 np.testing.assert_array_equal(res[r][key], ref[key], err_msg=f"rank {r}: {key}")
             else:
                 np.testing.assert_allclose(res[r][key], ref[key], rtol=2e-4, atol=1e-6, err_msg=f"rank {r}: {key}")
+    if defer and not zero1:
+        # the per-step gather carried 58 of the 60 floats per row (the dense form; steps whose union of visible rows is small
+        # take the sparse gather, which moves everything)
+        P0 = 150
+        dense_58 = [g for g in res[0]["gathered"] if g == (P0 - P0 // world) * 58 * 4]
+        assert dense_58 or all(g < (P0 - P0 // world) * 58 * 4 for g in res[0]["gathered"][:DENSIFY_STEPS]), res[0]["gathered"]
     # the edit did all three things: rows were cloned and split (more rows than kept ones) and pruned
     assert after > before - (before + 6) // 7
