@@ -60,6 +60,7 @@ SIGNATURES = {
     "g4s_get_option": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
     "g4s_pack_rows": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "g4s_accumulate_rows": (c_i, [c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "g4s_accumulate_rows_ordered": (c_i, [c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "g4s_profile_enable": (None, [c_i]),
     "g4s_profile_kernels": (c_i, []),
     "g4s_profile_name": (ctypes.c_char_p, [c_i]),

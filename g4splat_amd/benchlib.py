@@ -106,7 +106,17 @@ def valu_report(pk, kernel_ms, lane):
     cpi = (pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS / insts) if pk.get("GRBM_GUI_ACTIVE") else None
     issue = round(min(1.0, FMA_CPI / cpi), 4) if cpi else None
     guide = round(min(1.0, GUIDE_FMA_CPI / cpi), 4) if cpi else None
+    extra = {}
+    if all(c in pk for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS")) and pk.get("GRBM_GUI_ACTIVE"):
+        # Round 6 (LAB_NOTES section 6): the waves' scalar, LDS and memory instructions take issue slots too, and the blend
+        # kernels sit at the SIMD's issue limit for their TOTAL count -- ~2.9 cycles per instruction of any kind against the
+        # 2.77 of independent FMA streams; a second independent chain per wave (software pipelining) bought 2.5 %
+        anyk = insts + float(pk["SQ_INSTS_SALU"]) + float(pk["SQ_INSTS_LDS"]) + float(pk.get("SQ_INSTS_VMEM_RD", 0)) + float(pk.get("SQ_INSTS_VMEM_WR", 0))
+        extra = {"wave_instructions_of_any_kind_per_launch": int(anyk),
+                 "cycles_per_instruction_of_any_kind": round(pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS / anyk, 3),
+                 "frac_of_issue_limit_any_kind": round(min(1.0, FMA_CPI / (pk["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS / anyk)), 4)}
     return {"wave_instructions_per_launch": int(insts),
+            **extra,
             "cycles_per_instruction_profiled": round(cpi, 3) if cpi else None,
             "full_rate_cycles_per_instruction": FMA_CPI,
             "guide_cycles_per_instruction": GUIDE_FMA_CPI,

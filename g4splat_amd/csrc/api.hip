@@ -960,10 +960,27 @@ extern "C" int g4s_pack_rows(int nseg, float* const* segments, const int* widths
 
 extern "C" int g4s_accumulate_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, int nsrc, const int* src_off,
                                                    const int* src_cnt, const float* packed, int row_lo, int row_hi,
-                                                   hipStream_t s);
+                                                   hipStream_t s, int own_pos);
+
+static int accumulate_rows_impl(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
+                                const int* src_counts, const float* packed, int row_lo, int row_hi, int own_position, void* stream_);
 
 extern "C" int g4s_accumulate_rows(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
                                    const int* src_counts, const float* packed, int row_lo, int row_hi, void* stream_) {
+    return accumulate_rows_impl(nseg, segments, widths, nsrc, src_offsets, src_counts, packed, row_lo, row_hi, 0, stream_);
+}
+
+extern "C" int g4s_accumulate_rows_ordered(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
+                                           const int* src_counts, const float* packed, int row_lo, int row_hi, int own_position,
+                                           void* stream_) {
+    t_err[0] = 0;
+    if (own_position < 0 || own_position > nsrc) return fail(G4S_ERR_INVALID_ARGUMENT, "0 <= own_position <= nsrc");
+    if (own_position != 0 && nsrc > 8) return fail(G4S_ERR_UNSUPPORTED, "the ordered accumulation takes at most 8 sources");
+    return accumulate_rows_impl(nseg, segments, widths, nsrc, src_offsets, src_counts, packed, row_lo, row_hi, own_position, stream_);
+}
+
+static int accumulate_rows_impl(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
+                                const int* src_counts, const float* packed, int row_lo, int row_hi, int own_position, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int debug = 0;
     t_err[0] = 0;
@@ -976,7 +993,8 @@ extern "C" int g4s_accumulate_rows(int nseg, float* const* segments, const int* 
     for (int i = 0; i < nsrc; i++)
         if (src_offsets[i] < 0 || src_counts[i] < 0) return fail(G4S_ERR_INVALID_ARGUMENT, "source %d: negative offset / count", i);
     if (nsrc == 0 || row_hi == row_lo) return G4S_OK;
-    if (g4s_accumulate_rows_launch_internal(nseg, segments, widths, nsrc, src_offsets, src_counts, packed, row_lo, row_hi, stream) != 0)
+    if (g4s_accumulate_rows_launch_internal(nseg, segments, widths, nsrc, src_offsets, src_counts, packed, row_lo, row_hi, stream,
+                                            own_position) != 0)
         return fail(G4S_ERR_UNSUPPORTED, "rows wider than 240 floats");
     CHECK_LAUNCH("accumulate_rows");
     return G4S_OK;

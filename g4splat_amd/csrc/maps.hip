@@ -363,6 +363,11 @@ constexpr int ACC_CHUNK = 64;  // (measured at the metric size, eight ranks: 32 
 struct AccSources {
     int off[8], cnt[8];  // rows [off, off + cnt) of the buffer came from source i (ascending row indices)
     int nsrc;
+    // the owner's own contribution (already in the segments' rows) takes position `own_pos` in the order of additions:
+    // 0 = first (own + s0 + s1 + ...), k = behind the first k sources (((0 + s0 + ... + s_{k-1}) + own) + s_k + ...): with the
+    // sources in rank order and own_pos = the owner's rank, every row is summed in RANK ORDER whoever owns it
+    // (g4s_accumulate_rows_ordered)
+    int own_pos;
 };
 __global__ void __launch_bounds__(256) accumulate_rows_kernel(RowSegs segs, AccSources src, const float* __restrict__ packed,
                                                               int row_lo, int row_hi) {
@@ -390,8 +395,13 @@ __global__ void __launch_bounds__(256) accumulate_rows_kernel(RowSegs segs, AccS
         }
         if (seg >= 0) {
             const float* sp = segs.ptr[seg] + (size_t)chunk_lo * w + col;
+            if (src.own_pos == 0) {
 #pragma unroll 4
-            for (int r = wave; r < rows; r += 4) s_tile[r * row_floats + f] = sp[(size_t)r * w];
+                for (int r = wave; r < rows; r += 4) s_tile[r * row_floats + f] = sp[(size_t)r * w];
+            } else {  // the owner's rows join the sum behind the first own_pos sources (below): start from zero
+#pragma unroll 4
+                for (int r = wave; r < rows; r += 4) s_tile[r * row_floats + f] = 0.0f;
+            }
         }
     }
     // each source's rows of this chunk: group g = 32 lanes searches source g for both ends at once
@@ -427,7 +437,27 @@ __global__ void __launch_bounds__(256) accumulate_rows_kernel(RowSegs segs, AccS
     __syncthreads();
     // Sources in order; a wave takes rows b0 + wave, + 4, ... of the source's sub-range, four of them in flight (a source
     // holds a row once: the waves never meet on a tile row).
-    for (int s = 0; s < src.nsrc; s++) {
+    for (int s = 0; s <= src.nsrc; s++) {
+        if (s == src.own_pos && s != 0) {  // (uniform) the owner's own rows, in their place in the order
+            for (int f0 = 0; f0 < row_floats; f0 += 64) {
+                const int f = f0 + lane;
+                int seg = -1, col = 0, w = 1;
+                {
+                    int base = 0;
+                    for (int g = 0; g < segs.nseg; g++) {
+                        if (f >= base && f < base + segs.width[g]) { seg = g; col = f - base; w = segs.width[g]; }
+                        base += segs.width[g];
+                    }
+                }
+                if (seg >= 0) {
+                    const float* sp = segs.ptr[seg] + (size_t)chunk_lo * w + col;
+#pragma unroll 4
+                    for (int r = wave; r < rows; r += 4) s_tile[r * row_floats + f] += sp[(size_t)r * w];
+                }
+            }
+            __syncthreads();
+        }
+        if (s == src.nsrc) break;
         const int b0 = s_b0[s], b1 = s_b1[s];
         const float* base = packed + (size_t)src.off[s] * buf_floats;
         for (int j0 = b0 + wave; j0 < b1; j0 += 16) {
@@ -481,7 +511,7 @@ __global__ void __launch_bounds__(256) accumulate_rows_kernel(RowSegs segs, AccS
 
 extern "C" int g4s_accumulate_rows_launch_internal(int nseg, float* const* ptrs, const int* widths, int nsrc, const int* src_off,
                                                    const int* src_cnt, const float* packed, int row_lo, int row_hi,
-                                                   hipStream_t s) {
+                                                   hipStream_t s, int own_pos) {
     g4s::RowSegs segs{};
     segs.nseg = nseg;
     int row_floats = 0;
@@ -490,9 +520,11 @@ extern "C" int g4s_accumulate_rows_launch_internal(int nseg, float* const* ptrs,
     const size_t lds = (size_t)g4s::ACC_CHUNK * row_floats * sizeof(float);
     if (lds > 60 * 1024) return -1;
     const int blocks = (row_hi - row_lo + g4s::ACC_CHUNK - 1) / g4s::ACC_CHUNK;
+    if (own_pos != 0 && nsrc > 8) return -2;  // (the ordered form needs all sources in one launch)
     for (int s0 = 0; s0 < nsrc; s0 += 8) {  // (more than eight sources: eight per launch, in order)
         g4s::AccSources src{};
         src.nsrc = nsrc - s0 < 8 ? nsrc - s0 : 8;
+        src.own_pos = own_pos;
         for (int i = 0; i < src.nsrc; i++) { src.off[i] = src_off[s0 + i]; src.cnt[i] = src_cnt[s0 + i]; }
         hipLaunchKernelGGL(g4s::accumulate_rows_kernel, dim3(blocks), dim3(256), lds, s, segs, src, packed, row_lo, row_hi);
     }

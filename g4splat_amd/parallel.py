@@ -198,6 +198,13 @@ class OwnerReduce:
         # Gather only the rows some rank saw when they are a minority (sparse_below x P): on 2 / 4 ranks the union of the
         # step's views is 39 % / 70 % of S3's rows and ONE / three xGMI links carry a whole shard per step otherwise.
         self.sparse_below = 0.6
+        # Rank order (round 6): a row's contributions are added in ascending RANK order whoever owns the row -- (((0 + g_0) +
+        # g_1) + ...) + g_{N-1}, the owner's own rows in their place -- instead of "the owner's first, then the others".  That
+        # is the order in which ONE process accumulating the same views one after the other sums them, so a step of N ranks
+        # with one view each reproduces single-process gradient accumulation BIT FOR BIT (tests/test_gpu_dp.py, test_dp_gloo.py).
+        # Costs nothing: the same one-launch kernel with its additions reordered (up to 8 sources = 9 ranks; beyond, and
+        # with rank_order = False, the owner's rows come first).
+        self.rank_order = True
         self.last_gather = None  # "dense" | "sparse": what the last finish(gather=True) did
         self._nonzero_static = hasattr(torch, "nonzero_static")
         # one RCCL group call for the per-tensor in-place gathers: probed ONCE, on a dummy tensor, and agreed on by all
@@ -384,9 +391,10 @@ class OwnerReduce:
     # (read + write of the arrived rows only): measured at the metric size, tools/micro/owner_local_cost.py
     ONE_LAUNCH_SOURCES = 4
 
-    def _accumulate_kernel(self, offs, cnts, buf):
-        """g4s_accumulate_rows (include/g4s_rasterizer.h): the rows of `buf` received from the sources (offs[i], cnts[i]) are
-        added to my shard of the row views, source after source, in one launch."""
+    def _accumulate_kernel(self, offs, cnts, buf, own_pos=0):
+        """g4s_accumulate_rows[_ordered] (include/g4s_rasterizer.h): the rows of `buf` received from the sources (offs[i],
+        cnts[i]) are added to my shard of the row views, source after source, in one launch; own_pos > 0: my own rows take
+        that position in the order of additions (rank order)."""
         import ctypes
         from . import _lib
         lib = _lib.load()
@@ -396,8 +404,12 @@ class OwnerReduce:
         lo, hi = self.bounds()
         with torch.cuda.device(self.dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-            rc = lib.g4s_accumulate_rows(k, ptrs, widths, n, (ctypes.c_int * n)(*offs), (ctypes.c_int * n)(*cnts),
-                                         ctypes.c_void_p(buf.data_ptr()), int(lo), int(hi), stream)
+            if own_pos:
+                rc = lib.g4s_accumulate_rows_ordered(k, ptrs, widths, n, (ctypes.c_int * n)(*offs), (ctypes.c_int * n)(*cnts),
+                                                     ctypes.c_void_p(buf.data_ptr()), int(lo), int(hi), int(own_pos), stream)
+            else:
+                rc = lib.g4s_accumulate_rows(k, ptrs, widths, n, (ctypes.c_int * n)(*offs), (ctypes.c_int * n)(*cnts),
+                                             ctypes.c_void_p(buf.data_ptr()), int(lo), int(hi), stream)
         if rc != 0:
             raise RuntimeError(f"g4s_accumulate_rows failed ({rc}): {_lib.last_error()}")
 
@@ -525,27 +537,56 @@ class OwnerReduce:
                     # one launch for all sources (g4s_accumulate_rows: the same additions in the same order as a launch
                     # per source, one read + write of my shard instead of one per source); every source's rows ascend by
                     # index -- the index list of begin() is sorted, and so are the rows the backward packs itself
-                    offs, cnts = [], []
+                    offs, cnts, own_pos = [], [], 0
                     for s_ in range(self.world):
                         if recv[s_] and s_ != self.rank:  # (prepacked: my own rows came back to me; they are already in place)
                             offs.append(o)
                             cnts.append(recv[s_])
+                            own_pos += 1 if s_ < self.rank else 0
                         o += recv[s_]
-                    if len(offs) >= self.ONE_LAUNCH_SOURCES:
+                    # rank order (see `rank_order`): my own rows join the sum behind the sources of lower rank.  With no such
+                    # source (own first is rank order) or a single source (two addends commute) the plain forms already are.
+                    ordered = self.rank_order and own_pos > 0 and 2 <= len(offs) <= 8
+                    if ordered:
+                        self._accumulate_kernel(offs, cnts, in_rows, own_pos)
+                    elif len(offs) >= self.ONE_LAUNCH_SOURCES:
                         self._accumulate_kernel(offs, cnts, in_rows)
                     else:  # few sources: a launch each touches only the rows that arrived, not the whole shard
                         for o_, c_ in zip(offs, cnts):
                             self._rows_kernel(None, c_, in_rows[o_:o_ + c_], 15)
                 else:
+                    lo_, hi_ = self.bounds()
+                    live = [s_ for s_ in range(self.world) if recv[s_] and s_ != self.rank]
+                    below = [s_ for s_ in live if s_ < self.rank]
+                    ordered = self.rank_order and below and len(live) >= 2
+                    # host tensors: the same order of additions as the device path (rank order: the sources below me into a
+                    # zero shard first, then my own rows, then the sources above me)
+                    acc = [torch.zeros(hi_ - lo_, w, dtype=r.dtype) for r, w in zip(self.rows, self.widths)] if ordered else None
+                    starts, o2 = {}, 0
                     for s_ in range(self.world):
-                        c = recv[s_]
-                        if c and s_ != self.rank:
-                            ridx = in_rows[o:o + c, W].contiguous().view(torch.int32).to(torch.int64)
-                            off = 0
-                            for r, w in zip(self.rows, self.widths):
-                                r.index_add_(0, ridx, in_rows[o:o + c, off:off + w])
-                                off += w
-                        o += c
+                        starts[s_] = o2
+                        o2 += recv[s_]
+
+                    def add_source(s_, targets, shift):
+                        c, o_ = recv[s_], starts[s_]
+                        ridx = in_rows[o_:o_ + c, W].contiguous().view(torch.int32).to(torch.int64) - shift
+                        off = 0
+                        for r, w in zip(targets, self.widths):
+                            r.index_add_(0, ridx, in_rows[o_:o_ + c, off:off + w])
+                            off += w
+                    if ordered:
+                        for s_ in below:
+                            add_source(s_, acc, lo_)
+                        for a_, r in zip(acc, self.rows):
+                            a_ += r[lo_:hi_]
+                        for s_ in live:
+                            if s_ > self.rank:
+                                add_source(s_, acc, lo_)
+                        for a_, r in zip(acc, self.rows):
+                            r[lo_:hi_] = a_
+                    else:
+                        for s_ in live:
+                            add_source(s_, self.rows, 0)
             if not gather:
                 return
             # every rank gets every reduced shard

@@ -340,6 +340,18 @@ int g4s_pack_rows(int nseg, float* const* segments, const int* widths, const lon
 int g4s_accumulate_rows(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
                         const int* src_counts, const float* packed, int row_lo, int row_hi, void* stream);
 
+/*
+ * The same with the owner's own contribution (what the segments' rows hold on entry) taking position `own_position` in the
+ * order of additions instead of the first: every element becomes ((0 + s_0 + ... + s_{k-1}) + own) + s_k + ... + s_{n-1},
+ * k = own_position (0 <= k <= nsrc <= 8; k = 0 is g4s_accumulate_rows).  With the sources in rank order and k = the owner's
+ * rank, a row is summed in RANK ORDER whichever rank owns it -- the order in which one process accumulating the same views one
+ * after the other sums them, so an N-rank step of the exchange reproduces single-process gradient accumulation bit for bit
+ * (g4splat_amd/parallel.py: OwnerReduce.rank_order).  Same traffic as g4s_accumulate_rows.
+ */
+int g4s_accumulate_rows_ordered(int nseg, float* const* segments, const int* widths, int nsrc, const int* src_offsets,
+                                const int* src_counts, const float* packed, int row_lo, int row_hi, int own_position,
+                                void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (used by bench.py
  * for the roofline figure; off by default, process-wide).  Kernel groups 0..g4s_profile_kernels()-1
  * are named by g4s_profile_name().  g4s_profile_read() synchronises on the recorded events and

@@ -221,6 +221,17 @@ def _owner_worker(rank, world, port, q):
             ok = bool(torch.equal(flat, dense))
         else:
             ok = bool((flat - dense).abs().max() <= 1e-6 * dense.abs().max())
+        # RANK ORDER (round 6): whatever the values and whoever owns a row, the result is (((0 + g_0) + g_1) + ...) + g_{N-1} --
+        # what one process accumulating the ranks' contributions one after the other computes -- bit for bit
+        mine = torch.zeros(P * 7)
+        mine[:3 * P].view(P, 3)[vis] = vals[vis, :3]
+        mine[3 * P:].view(P, 4)[vis] = vals[vis, 3:]
+        everyone = [torch.zeros(P * 7) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        seq = torch.zeros(P * 7)
+        for g_r in everyone:
+            seq += g_r
+        ok = ok and bool(torch.equal(flat, seq))
         # determinism of the owner's summation order: a second exchange of the same inputs gives the same bits
         flat2 = torch.zeros(P * 7)
         rows2 = [flat2[:3 * P].view(P, 3), flat2[3 * P:].view(P, 4)]
@@ -264,7 +275,9 @@ def _owner_worker(rank, world, port, q):
 def test_owner_reduce_equals_dense_all_reduce(world):
     """OwnerReduce (all_to_all of visible rows to index-shard owners, all_gather of the reduced shards) against the dense
     SUM all-reduce: bit-identical on exactly representable values at 2, 4 and 8 ranks (ragged last shard, empty and full
-    visibility included), bit-identical on arbitrary values at 2 ranks, equal to rounding at 4 and 8, and bit-reproducible."""
+    visibility included), bit-identical on arbitrary values at 2 ranks, equal to rounding at 4 and 8, and bit-reproducible;
+    and at every world size, for arbitrary values, THE SAME BITS as adding the ranks' contributions one after the other in
+    rank order (`OwnerReduce.rank_order`: an N-rank step reproduces single-process gradient accumulation)."""
     _setup_paths()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

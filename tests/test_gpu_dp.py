@@ -802,17 +802,20 @@ def _dz_pack(model, exp_avg, exp_avg_sq, history):
                 denom=n(model.denom), radii=n(model.max_radii2D), history=history)
 
 
-def _dz_worker(rank, world, port, q):
+def _dz_worker(rank, world, port, q, backend="gloo"):
     root = os.path.dirname(HERE)
     for p in (root, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from g4splat_amd.parallel import ReplicatedDensification, ViewParallel
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from g4splat_amd.parallel import ReplicatedDensification, ViewParallel
     model, cams, targets, cfg, bg = _dz_scene(dev)
     vp = ViewParallel(model.parameters(), exchange="owner")
     opt = vp.sharded_adam([g["lr"] for g in model.optimizer.param_groups])
@@ -831,51 +834,35 @@ def _dz_worker(rank, world, port, q):
             history.append((before, model._xyz.shape[0]))
     ea, es = opt.full_state()
     torch.cuda.synchronize()
-    q.put((rank, _dz_pack(model, ea, es, history)))
+    out = _dz_pack(model, ea, es, history)
+    out["rccl"] = bool(vp._ensure_owner().rccl)
+    q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def _dz_single_process(world):
-    """The data-parallel schedule written out in ONE process with no exchange code: the eight views' gradients taken one
-    by one, summed per owner shard in the exchange's order (the owner's own view first, then the others by ascending rank:
-    float addition is not associative, and this is the association N ranks produce), FusedAdam over the full tensors, the
-    statistics likewise, densify_and_prune with the iteration's generator on the model's own (replicated) optimiser state."""
+    """The same schedule in ONE process with no exchange code at all: the `world` views rendered one after the other, their
+    gradients ACCUMULATED by autograd into one bucket (and the per-view statistics summed) in view order, FusedAdam over the
+    full tensors, densify_and_prune with the iteration's generator on the model's own optimiser state.  The owner exchange
+    sums every row in rank order (OwnerReduce.rank_order), which is this order -- so the comparison is bit for bit."""
     from g4splat_amd.parallel import ViewParallel, densify_generator
     dev = torch.device("cuda", 0)
     model, cams, targets, cfg, bg = _dz_scene(dev)
     vp = ViewParallel(model.parameters())
     history = []
     for it in range(1, 2 * DZ_STEPS + 1):
-        P = model._xyz.shape[0]
-        per_view = []
         for r in range(world):
-            vp.zero()
             out = _dz_view_step(model, cams[r], targets[r], cfg, bg)
             vp.record_view(out["viewspace_points"], out["visibility_filter"], out["radii"])
-            per_view.append(([v.clone() for v in vp.bucket.views], vp.grad_norm_sum.clone(), vp.vis_count.clone(), vp.max_radii.clone()))
-        shard = (P + world - 1) // world
         with torch.no_grad():
-            sums = [torch.zeros_like(v) for v in vp.bucket.views] + [torch.zeros_like(vp.grad_norm_sum), torch.zeros_like(vp.vis_count)]
-            for d in range(world):
-                lo, hi = min(d * shard, P), min((d + 1) * shard, P)
-                for k, acc in enumerate(sums):
-                    src = lambda r: (per_view[r][0][k] if k < len(vp.bucket.views) else per_view[r][1 + k - len(vp.bucket.views)])
-                    acc[lo:hi] = src(d)[lo:hi]
-                    for r in range(world):
-                        if r != d:
-                            acc[lo:hi] += src(r)[lo:hi]
-            for v, sgrad in zip(vp.bucket.views, sums):
-                v.copy_(sgrad)
             model.optimizer.step()
-            model.xyz_gradient_accum += sums[-2]
-            model.denom += sums[-1]
-            rmax = per_view[0][3]
-            for r in range(1, world):
-                rmax = torch.maximum(rmax, per_view[r][3])
-            model.max_radii2D = torch.maximum(model.max_radii2D, rmax)
+            model.xyz_gradient_accum += vp.grad_norm_sum
+            model.denom += vp.vis_count
+            model.max_radii2D = torch.maximum(model.max_radii2D, vp.max_radii)
+            vp.zero()
             if it == DZ_STEPS:
-                before = P
+                before = model._xyz.shape[0]
                 model.densify_and_prune(generator=densify_generator(dev, it, 11), **_dz_densify_args(model))
                 vp.rebind(model.parameters())
                 history.append((before, model._xyz.shape[0]))
@@ -891,7 +878,8 @@ def test_densify_and_prune_on_every_replica_with_eight_ranks_on_one_gpu(world):
     compaction kernels of densify.py, torch.normal on the device from the iteration's generator).  Three ZeRO-1 steps, ONE
     densify_and_prune on every replica (clone + split + prune + screen-size limit; the Adam moments gathered for the edit
     and re-sharded for the new row count), three more steps.  Parameters, moments and statistics: the same bits on all
-    eight ranks, and the same bits as the single-process run that writes the data-parallel sums out by hand."""
+    eight ranks, and THE SAME BITS AS ONE PROCESS THAT ACCUMULATES THE EIGHT VIEWS ONE AFTER THE OTHER (plain autograd
+    accumulation, FusedAdam, no exchange code): the owner exchange sums every row in rank order."""
     import numpy as np
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -912,3 +900,22 @@ def test_densify_and_prune_on_every_replica_with_eight_ranks_on_one_gpu(world):
             assert np.array_equal(res[r][key], res[0][key]), f"rank {r} differs from rank 0 in {key}"
             assert np.array_equal(res[r][key], ref[key]), (f"rank {r} differs from the single-process run in {key}",
                                                            float(np.abs(res[r][key] - ref[key]).max()))
+
+
+def test_densify_and_prune_through_the_rccl_backend():
+    """The same schedule with every collective executed BY RCCL (backend nccl, the world size a one-GPU box allows): the
+    radii MAX, the zero-split all_to_all, the owner step, the grouped in-place all_gather of the parameters, the all-gather of
+    the Adam moments for the edit and their re-sharding run on RCCL's persistent-buffer path; the result equals the
+    single-process run bit for bit."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dz_worker, args=(0, 1, 44500 + (os.getpid() % 2000), q, "nccl"))
+    p.start()
+    _rank, res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and res["rccl"]
+    ref = _dz_single_process(1)
+    assert res["history"] == ref["history"] and ref["history"][0][0] != ref["history"][0][1]
+    for key in ("params", "exp_avg", "exp_avg_sq", "accum", "denom", "radii"):
+        assert np.array_equal(res[key], ref[key]), key

@@ -41,7 +41,9 @@ if len(sys.argv) >= 4:
         if key and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
             kern[key] = {"FETCH_SIZE": round(agg[k]["FETCH_SIZE"] / max(cnt[k]["FETCH_SIZE"], 1), 1),
                          "WRITE_SIZE": round(agg[k]["WRITE_SIZE"] / max(cnt[k]["WRITE_SIZE"], 1), 1)}
-            for c in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):  # VALU issue rate (the blend kernels' real bound)
+            # instruction counts by kind + active cycles: the blend kernels are bound by how many instructions of ANY kind
+            # their waves issue (LAB_NOTES section 6), not by HBM
+            for c in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
                 if c in agg[k]:
                     kern[key][c] = round(agg[k][c] / max(cnt[k][c], 1), 1)
     # frames small enough for the four-wave backward throughout (<= 768 tiles, e.g. S1) never launch blend_bwd_kernel:
