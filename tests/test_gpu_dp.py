@@ -258,6 +258,36 @@ def test_all_sources_accumulated_in_one_launch_equal_one_launch_per_source():
         for x, y, z in zip(a, b, host):
             assert torch.equal(x, y), (P, lo, hi, nsrc)
             assert np.array_equal(y.cpu().numpy(), z), (P, lo, hi, nsrc)
+        # g4s_accumulate_rows_ordered: the owner's own rows at position k of the order of additions -- every element is
+        # ((0 + s_0 + ... + s_{k-1}) + own) + s_k + ..., against the same sequence of float32 additions on the host
+        live = [(o, c, ix) for o, c, ix in zip(offs, counts, idx) if c]
+        if 1 <= len(live) <= 8:
+            n = len(live)
+            for own_pos in sorted({0, 1, n // 2, n}):
+                c_rows = [r.clone() for r in base]
+                ptrs = (ctypes.c_void_p * k)(*[r.data_ptr() for r in c_rows])
+                rc = lib.g4s_accumulate_rows_ordered(k, ptrs, wid, n, (ctypes.c_int * n)(*[o for o, _, _ in live]),
+                                                     (ctypes.c_int * n)(*[c for _, c, _ in live]), ctypes.c_void_p(buf.data_ptr()),
+                                                     lo, hi, own_pos, stream)
+                assert rc == 0, _lib.last_error()
+                torch.cuda.synchronize()
+                want = [r.cpu().numpy().copy() for r in base]
+                acc = [np.zeros((hi - lo, w), np.float32) for w in widths]
+                for pos in range(n + 1):
+                    if pos == own_pos:
+                        for a_, r in zip(acc, want):
+                            a_ += r[lo:hi]
+                    if pos == n:
+                        break
+                    o, c, ix = live[pos]
+                    off = 0
+                    for a_, w in zip(acc, widths):
+                        a_[ix - lo] = a_[ix - lo] + hb[o:o + c, off:off + w]
+                        off += w
+                for a_, r in zip(acc, want):
+                    r[lo:hi] = a_
+                for y, z in zip(c_rows, want):
+                    assert np.array_equal(y.cpu().numpy(), z), (P, lo, hi, nsrc, own_pos)
 
 
 # (strong scaling at two ranks -- four views per rank accumulated locally -- moved behind `-m "gpu and exhaustive"` in round 5:
