@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B of library variants: bit-identity (tools/grad_digest.py) + kernel times (bench.py, S3 and S2), two alternating rounds
-# usage: tools/r06_ab.sh out.txt var/a.so var/b.so ...
-out=gpurun_out/r06/$1; shift
-mkdir -p gpurun_out/r06; : > $out
+# usage: tools/ab_digest_and_time.sh out.txt var/a.so var/b.so ...
+out=gpurun_out/${ROUND:-r06}/$1; shift
+mkdir -p gpurun_out/${ROUND:-r06}; : > $out
 keep=$(mktemp); cp g4splat_amd/libg4s_hip.so "$keep"
 for v in "$@"; do
   cp "$v" g4splat_amd/libg4s_hip.so; touch g4splat_amd/libg4s_hip.so

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """What a given AFFINE_TOL (csrc/g4s_device.h: the bound the REC_AFFINE certificate puts on the affine form's alpha)
-costs and buys -- for the library that is currently installed (run on the GPU box; tools/r06_affine_tol.sh installs
+costs and buys -- for the library that is currently installed (run on the GPU box; tools/rounds/r06_affine_tol.sh installs
 the variants one after the other):
 
     python tools/affine_tol_sweep.py <margin> [s1] [s3] [s3t]
