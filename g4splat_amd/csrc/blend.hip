@@ -23,6 +23,11 @@
 #include "g4s_internal.h"
 #include "g4s_device.h"
 
+// visits of the blend forward per test of "is the quadrant saturated?" (1, 2, 4 or 8; profiles/r06_ab_bitclear.txt)
+#ifndef G4S_FWD_PAIRS
+#define G4S_FWD_PAIRS 4
+#endif
+
 namespace g4s {
 
 // Which of the tile's four 8x8-pixel quadrants -- columns 2 tile_x + {0, 1}, rows 2 tile_y + {0, 1} -- the splat's
@@ -182,21 +187,61 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
             uint64_t todo = __ballot(rel);
             const uint64_t nolp_mask = __ballot((rbits & 16u) != 0);  // wave-uniform, one bit per staged entry
             uint64_t hit = 0;  // wave-uniform: entries of this group blended by some pixel of this quadrant
+            // One visit: the next staged entry of this group that can reach the quadrant.  (A macro, not a lambda: with `todo`
+            // and `hit` captured by reference hipcc keeps copies of them and the loop grows by eight instructions.)
+            // The visited bit is cleared with ONE s_andn2_b64 against the mask the hit / nolp tests form anyway; `todo &= todo - 1`
+            // is s_add_u32, s_addc_u32, s_and_b64.  Every instruction of this loop, scalar ones included, is ~1.2 % of the kernel
+            // (the waves issue at the SIMD's limit for their instruction COUNT, LAB_NOTES section 6): blend_fwd 0.414 -> 0.400 ms
+            // (profiles/r06_ab_bitclear.txt).
+#define G4S_FWD_VISIT()                                                                                                          \
+    do {                                                                                                                         \
+        const int bit = (int)__builtin_ctzll(todo);                                                                              \
+        const int j = g0 + bit;                                                                                                  \
+        todo &= ~(1ull << bit);                                                                                                  \
+        const uint32_t contributor = (uint32_t)(b0 + j + 1); /* the reference's 1-based list position (forward.cu:349) */        \
+        const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];                    \
+        const bool nolp = (nolp_mask >> bit) & 1ull; /* scalar */                                                                \
+        fwd_visit(st, nolp, pxf, pyf, q0, q1, q2, q3, q4, contributor);                                                          \
+        /* blended by some pixel <=> some pixel's last_contributor is this entry */                                             \
+        if (__ballot(st.last_contributor == contributor) != 0ull) hit |= 1ull << bit;                                            \
+    } while (0)
+#if G4S_FWD_PAIRS >= 2
+            // Several visits per test of "is the quadrant saturated?" (a compare, a scalar test, a select, a mask and a branch
+            // per visit otherwise): at worst G4S_FWD_PAIRS - 1 visits run on a quadrant that has just saturated -- they blend
+            // nothing (Tt == 0 in every lane) and change nothing.  Per visit of 1 / 2 / 4 / 8: blend_fwd 0.401 / 0.394 / 0.388 /
+            // 0.388 ms (bit-identical; profiles/r06_ab_bitclear.txt).
+            while (todo) {
+                G4S_FWD_VISIT();
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+#if G4S_FWD_PAIRS >= 4
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+#endif
+#if G4S_FWD_PAIRS >= 8
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+                if (todo == 0ull) break;
+                G4S_FWD_VISIT();
+#endif
+                if (__ballot(st.Tt != 0.0f) == 0ull) break;
+            }
+            const bool live = __ballot(st.Tt != 0.0f) != 0ull;
+#else
             bool live = true;  // wave-uniform: some pixel of the quadrant is not saturated yet
             while (todo) {
-                const int bit = (int)__builtin_ctzll(todo);
-                const int j = g0 + bit;
-                todo &= todo - 1;
-                // `contributor` of the reference = 1-based list position (forward.cu:349)
-                const uint32_t contributor = (uint32_t)(b0 + j + 1);
-                const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
-                const bool nolp = (nolp_mask >> bit) & 1ull;  // scalar
-                fwd_visit(st, nolp, pxf, pyf, q0, q1, q2, q3, q4, contributor);
-                // blended by some pixel <=> some pixel's last_contributor is this entry
-                if (__ballot(st.last_contributor == contributor) != 0ull) hit |= 1ull << bit;
+                G4S_FWD_VISIT();
                 live = __ballot(st.Tt != 0.0f) != 0ull;
                 if (!live) break;
             }
+#endif
+#undef G4S_FWD_VISIT
             if (lane == 0 && hit) s_hit[g0 >> 6][wv] = hit;
             n_blended += (uint32_t)__builtin_popcountll(hit);
             if (!live) break;
@@ -389,7 +434,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
         const uint64_t nolp_mask = __ballot(nolp_l);  // wave-uniform: REC_AFFINE entries
         while (todo) {
             const int j = (int)__builtin_ctzll(todo);
-            todo &= todo - 1;
+            todo &= ~(1ull << j);  // (one s_andn2_b64 instead of the three instructions of `todo & (todo - 1)`, see the forward)
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)qmask, j);  // wave-uniform
             const bool nolp = (nolp_mask >> j) & 1ull;                               // scalar
             // == !nolp, in an SGPR and opaque to the optimiser (see the gradient block)
@@ -666,7 +711,7 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
             uint64_t lp_mask = 0;  // wave-uniform
             while (todo) {
                 const int j = (int)__builtin_ctzll(todo);
-                todo &= todo - 1;
+                todo &= ~(1ull << j);
                 const bool nolp = (nolp_mask >> j) & 1ull;
                 const uint32_t general = (uint32_t)__builtin_amdgcn_readfirstlane(nolp ? 0 : 1);  // (see the one-wave kernel)
                 const uint32_t pos = (uint32_t)(hi - 1 - j);
