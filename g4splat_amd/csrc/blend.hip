@@ -187,6 +187,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
             uint64_t todo = __ballot(rel);
             const uint64_t nolp_mask = __ballot((rbits & 16u) != 0);  // wave-uniform, one bit per staged entry
             uint64_t hit = 0;  // wave-uniform: entries of this group blended by some pixel of this quadrant
+            const uint32_t contributor0 = (uint32_t)(b0 + g0 + 1);
+            uint32_t rec_base = (uint32_t)g0 * 16u;  // byte offset of the group's first record inside a quad's row
+            asm volatile("" : "+v"(rec_base));       // (a vector register on purpose, see the visit)
             // One visit: the next staged entry of this group that can reach the quadrant.  (A macro, not a lambda: with `todo`
             // and `hit` captured by reference hipcc keeps copies of them and the loop grows by eight instructions.)
             // The visited bit is cleared with ONE s_andn2_b64 against the mask the hit / nolp tests form anyway; `todo &= todo - 1`
@@ -196,10 +199,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
 #define G4S_FWD_VISIT()                                                                                                          \
     do {                                                                                                                         \
         const int bit = (int)__builtin_ctzll(todo);                                                                              \
-        const int j = g0 + bit;                                                                                                  \
         todo &= ~(1ull << bit);                                                                                                  \
-        const uint32_t contributor = (uint32_t)(b0 + j + 1); /* the reference's 1-based list position (forward.cu:349) */        \
-        const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];                    \
+        const uint32_t contributor = contributor0 + (uint32_t)bit; /* the reference's 1-based list position (forward.cu:349) */  \
+        /* the record's LDS address in ONE instruction (v_lshl_add_u32 from the group's base, kept in a VGPR) */                 \
+        const float4* rq_ = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(&s_rec[0][0]) + (rec_base + ((uint32_t)bit << 4))); \
+        const float4 q0 = rq_[0], q1 = rq_[FWD_BATCH], q2 = rq_[2 * FWD_BATCH], q3 = rq_[3 * FWD_BATCH], q4 = rq_[4 * FWD_BATCH];   \
         const bool nolp = (nolp_mask >> bit) & 1ull; /* scalar */                                                                \
         fwd_visit(st, nolp, pxf, pyf, q0, q1, q2, q3, q4, contributor);                                                          \
         /* blended by some pixel <=> some pixel's last_contributor is this entry */                                             \
