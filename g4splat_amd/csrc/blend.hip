@@ -207,7 +207,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
         const bool nolp = (nolp_mask >> bit) & 1ull; /* scalar */                                                                \
         fwd_visit(st, nolp, pxf, pyf, q0, q1, q2, q3, q4, contributor);                                                          \
         /* blended by some pixel <=> some pixel's last_contributor is this entry */                                             \
-        if (__ballot(st.last_contributor == contributor) != 0ull) hit |= 1ull << bit;                                            \
+        if (__ballot(st.last_contributor == contributor) != 0ull) {                                                              \
+            hit |= 1ull << bit;                                                                                                  \
+            asm volatile(""); /* keeps this a branch around ONE s_or_b64: as a select it is two s_cselect_b32 + the s_or */        \
+        }                                                                                                                        \
     } while (0)
 #if G4S_FWD_PAIRS >= 2
             // Several visits per test of "is the quadrant saturated?" (a compare, a scalar test, a select, a mask and a branch
