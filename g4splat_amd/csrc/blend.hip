@@ -75,11 +75,14 @@ __device__ __forceinline__ bool quad_misses_region(const float4 q0, const float4
 constexpr int FWD_BATCH = 256;
 
 struct FwdPixel {
-    // Tt = running transmittance while the pixel is live, 0 once it is saturated (forward.cu:327,399 `done`) or
-    // when it lies outside the image: a dead pixel then fails `test_T >= 1e-4` by itself, so the loop needs no
-    // per-lane `done` predicate, and "all 64 pixels dead" is one v_cmp of Tt against 0.  T_done keeps the
-    // transmittance a saturated pixel had when it stopped (the value the reference leaves in T).
-    float Tt, T_done;
+    // Tt = running transmittance while the pixel is live; once it is saturated (forward.cu:327,399 `done`) Tt = -T, the
+    // NEGATED transmittance it had when it stopped (the value the reference leaves in T), and a pixel outside the image
+    // starts at 0: a dead pixel then fails `test_T >= 1e-4` by itself (test_T <= 0), so the loop needs no per-lane `done`
+    // predicate, "all 64 pixels dead" is one v_cmp of Tt against 0, saturating is ONE select (Tt = stop ? -|T| : test_T:
+    // the sign and magnitude operand modifiers are free), and the final transmittance is |Tt| either way.  (Until round 6 a
+    // dead pixel carried Tt = 0 and a second register kept its last T: one more compare, one more select and the join
+    // copies of a two-armed branch per visit.)
+    float Tt;
     uint32_t last_contributor, median_contributor;
     float C0, C1, C2, N0, N1, N2, Dd, M1, M2, distortion, median_depth;
 };
@@ -94,9 +97,10 @@ __device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, flo
         const float alpha = e.alpha, depth = e.depth;
         const float T = p.Tt;
         const float test_T = T * (1 - alpha);
+        // Both arms update Tt (and the blending arm last_contributor) IN PLACE, as asm: written as assignments, the two
+        // definitions meet in fresh registers and every visit pays four copies at the join.
         if (test_T < 0.0001f) {
-            if (T != 0.0f) p.T_done = T;
-            p.Tt = 0.0f;
+            asm volatile("v_or_b32 %0, 0x80000000, %0" : "+v"(p.Tt));  // dead from here on: -|T|
         } else {
             const float w = alpha * T;
             const float A = 1 - T;
@@ -116,8 +120,8 @@ __device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, flo
             p.C0 = fmaf(q4.y, w, p.C0);
             p.C1 = fmaf(q4.z, w, p.C1);
             p.C2 = fmaf(q4.w, w, p.C2);
-            p.Tt = test_T;
-            p.last_contributor = contributor;
+            asm volatile("v_mov_b32 %0, %1" : "+v"(p.Tt) : "v"(test_T));
+            asm volatile("v_mov_b32 %0, %1" : "+v"(p.last_contributor) : "s"(contributor));
         }
     }
 }
@@ -143,13 +147,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
 
     FwdPixel st{};
     st.Tt = inside ? 1.0f : 0.0f;
-    st.T_done = 1.0f;
     uint32_t n_blended = 0;  // wave-uniform: (entry, this quadrant) pairs some pixel blended = the backward's visits
     uint32_t n_entries = 0;  // wave-uniform: staged entries (of this wave's share of every batch) that some pixel blended
 
     for (int b0 = 0; b0 < n; b0 += FWD_BATCH) {
         // end if the entire tile is saturated (forward.cu:327)
-        if (__syncthreads_count(st.Tt == 0.0f) == 256) break;
+        if (__syncthreads_count(!(st.Tt > 0.0f)) == 256) break;
         const int m = imin_(FWD_BATCH, n - b0);
         if ((int)threadIdx.x < m) {
             const uint64_t e = a.entries[r0 + b0 + threadIdx.x];
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
         }
         if (threadIdx.x < (FWD_BATCH / 64) * 4) (&s_hit[0][0])[threadIdx.x] = 0ull;
         __syncthreads();
-        if (__ballot(st.Tt != 0.0f) != 0ull) {
+        if (__ballot(st.Tt > 0.0f) != 0ull) {
         // Each group of 64 staged entries is filtered for this wave's quadrant with one bit test per lane + a
         // ballot; only entries whose region touches the quadrant are visited (scalar bit scan), so a rejected
         // entry costs ~1/64 of a loop iteration.
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
 #if G4S_FWD_PAIRS >= 2
             // Several visits per test of "is the quadrant saturated?" (a compare, a scalar test, a select, a mask and a branch
             // per visit otherwise): at worst G4S_FWD_PAIRS - 1 visits run on a quadrant that has just saturated -- they blend
-            // nothing (Tt == 0 in every lane) and change nothing.  Per visit of 1 / 2 / 4 / 8: blend_fwd 0.401 / 0.394 / 0.388 /
+            // nothing (Tt <= 0 in every lane) and change nothing.  Per visit of 1 / 2 / 4 / 8: blend_fwd 0.401 / 0.394 / 0.388 /
             // 0.388 ms (bit-identical; profiles/r06_ab_bitclear.txt).
             while (todo) {
                 G4S_FWD_VISIT();
@@ -237,14 +240,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
                 if (todo == 0ull) break;
                 G4S_FWD_VISIT();
 #endif
-                if (__ballot(st.Tt != 0.0f) == 0ull) break;
+                if (__ballot(st.Tt > 0.0f) == 0ull) break;
             }
-            const bool live = __ballot(st.Tt != 0.0f) != 0ull;
+            const bool live = __ballot(st.Tt > 0.0f) != 0ull;
 #else
             bool live = true;  // wave-uniform: some pixel of the quadrant is not saturated yet
             while (todo) {
                 G4S_FWD_VISIT();
-                live = __ballot(st.Tt != 0.0f) != 0ull;
+                live = __ballot(st.Tt > 0.0f) != 0ull;
                 if (!live) break;
             }
 #endif
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))
         a.tile_depth[2 * tile] = 0u;
         a.tile_depth[2 * tile + 1] = (uint32_t)((v[0] + v[1]) + (v[2] + v[3]));
     }
-    const float T = st.Tt != 0.0f ? st.Tt : st.T_done;
+    const float T = fabsf(st.Tt);
     if (inside) {
         a.final_T[pix_id] = T;
         a.final_T[pix_id + N] = st.M1;
