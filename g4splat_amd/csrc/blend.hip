@@ -110,9 +110,11 @@ __device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, flo
             p.Dd = fmaf(depth, w, p.Dd);
             p.M1 = fmaf(md, w, p.M1);
             p.M2 = fmaf(md2, w, p.M2);
+            // (last_contributor first, in place; the median select then reads it instead of a second copy of `contributor`)
+            asm volatile("v_mov_b32 %0, %1" : "+v"(p.last_contributor) : "s"(contributor));
             if (T > 0.5f) {
                 p.median_depth = depth;
-                p.median_contributor = contributor;
+                p.median_contributor = p.last_contributor;
             }
             p.N0 = fmaf(q1.x, w, p.N0);
             p.N1 = fmaf(q1.y, w, p.N1);
@@ -121,7 +123,6 @@ __device__ __forceinline__ void fwd_visit(FwdPixel& p, bool nolp, float pxf, flo
             p.C1 = fmaf(q4.z, w, p.C1);
             p.C2 = fmaf(q4.w, w, p.C2);
             asm volatile("v_mov_b32 %0, %1" : "+v"(p.Tt) : "v"(test_T));
-            asm volatile("v_mov_b32 %0, %1" : "+v"(p.last_contributor) : "s"(contributor));
         }
     }
 }

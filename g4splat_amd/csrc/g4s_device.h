@@ -411,7 +411,7 @@ __device__ __forceinline__ bool eval_pair(bool affine, float pxf, float pyf, flo
     // v_rcp_f32), and where p'.x is exactly 0 on the same pixel 0 x inf = NaN would survive fminf(0.99, NaN) as alpha = 0.99;
     // the reference divides and gets s = 0 there.  (|p'.z| < 1e-38 means a depth beyond 1e38: the horizon of the splat's plane.)
     bool ok = fabsf(ppz) >= 1.17549435e-38f;
-    if (!affine) {  // forward.cu:355-378 with (c0..c2) = Tu, (c3..c5) = Tv, (c6..c8) = Tw
+    if (__builtin_expect(!affine, 0)) {  // forward.cu:355-378 with (c0..c2) = Tu, (c3..c5) = Tv, (c6..c8) = Tw  (out of line: the common path falls through)
         const float kx = fmaf(pxf, c6, -c0), ky = fmaf(pxf, c7, -c1), kz = fmaf(pxf, c8, -c2);
         const float lx = fmaf(pyf, c6, -c3), ly = fmaf(pyf, c7, -c4), lz = fmaf(pyf, c8, -c5);
         ppx = fmaf(ky, lz, -(kz * ly));
