@@ -465,7 +465,11 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
             asm volatile("" : "+v"(gc0), "+v"(gc1), "+v"(gc2), "+v"(gn0), "+v"(gn1), "+v"(gn2));
             asm volatile("" : "+v"(gt0), "+v"(gt1), "+v"(gt2), "+v"(gt3), "+v"(gt4), "+v"(gt5), "+v"(gt6), "+v"(gt7), "+v"(gt8));
             asm volatile("" : "+v"(gop), "+v"(glp0), "+v"(glp1));
-            bool lowpass = false;
+            // "some pixel took the low-pass branch" as a REGISTER a pixel writes when it does (non-affine entries only), not as a
+            // bool: a bool set in a divergent arm and carried across the four visits is a lane mask that every visit merges
+            // (s_mov, s_andn2, s_and, s_or -- four scalar instructions on the common path for a flag only the rare path sets)
+            float lowpass = 0.0f;
+            asm volatile("" : "+v"(lowpass));
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!((qm >> q) & 1u)) continue;  // scalar branch
@@ -574,7 +578,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                         glp0 = fmaf(c2, e.dx, glp0);
                         glp1 = fmaf(c2, e.dy, glp1);
                         gt8 += dL_dz;  // depth = Tw.z here, and on the general path term 14 is dL/dTw.z
-                        lowpass = true;
+                        asm volatile("v_mov_b32 %0, 1.0" : "+v"(lowpass));
                     }
                     }
                     gop = fmaf(G, dL_dalpha, gop);
@@ -594,7 +598,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                 const float y = wave_sum16_to_quads(t, lane_b3, lane_b2);
                 const bool slot_ok = slot < a.n_slots;  // false only in a frame that overflowed its presized capacity
                 if (quad_writer && slot_ok) rec[term_of_lane] = y;  // sixteen lanes, sixteen consecutive floats
-                const bool lp = __any(lowpass);
+                const bool lp = __ballot(lowpass != 0.0f) != 0ull;
                 if (lp) {
                     const float r4 = wave_sum4_to_rows(glp0, glp1, 0.0f, 0.0f);
                     if (row_writer && slot_ok) rec[16 + row] = r4;
