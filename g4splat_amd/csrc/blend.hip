@@ -357,7 +357,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
     const int px0 = tx0 + (lane & 7), py0 = ty0 + (lane >> 3);
     const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
     BwdPixelLite p[4];
-    uint32_t max_last = 0, max_median = 0;
+    uint32_t max_last = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
@@ -388,7 +388,6 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
         s_med[q * 64 + lane] = make_float2(__uint_as_float(median_c), dL_dmedian);
         x.T = T_final;
         max_last = max(max_last, x.last_c);  // pixels outside the image keep last_c = 0: never active
-        max_median = max(max_median, median_c);
     }
     const float mscale = FAR_N / (FAR_N - NEAR_N);
     const float dmd_k = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);  // m = mscale - dmd_k / depth, dm/ddepth = dmd_k / depth^2
@@ -402,8 +401,6 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
     // (readfirstlane: the two maxima are wave-uniform, and what derives from them -- hi, m, pos, the median test --
     // belongs in SGPRs: scalar compares and branches instead of vector compares inside EXEC regions)
     const int n_live = __builtin_amdgcn_readfirstlane((int)wave_max_u32(max_last));
-    // 1-based list position of the deepest median contributor of the tile: entries behind it skip the median term
-    const uint32_t tile_max_median = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(max_median));
     if (n_live > a.hot_threshold) {  // a deep tile would be this kernel's tail: four waves take it (blend_bwd_hot_kernel)
         if (lane == 0) a.hot_list[atomicAdd(a.hot_count, 1u)] = (uint32_t)tile;
         return;
@@ -475,6 +472,10 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                 if (!((qm >> q) & 1u)) continue;  // scalar branch
                 BwdPixelLite& x = p[q];
                 const float4 cst = s_cst[q * 64 + lane];
+                // (the median position and its cotangent: read with cst on every visit and SELECTED below.  A scalar branch
+                // around the read for entries behind the tile's deepest median was three instructions when not taken and
+                // eight when taken -- half the visits --, the read + compare + select are four: blend_bwd 0.773 -> 0.762 ms)
+                const float2 md = s_med[q * 64 + lane];
                 const float pxf = (float)(px0 + (q & 1) * 8), pyf = (float)(py0 + (q >> 1) * 8);
                 PairEval e;
                 // eval_pair runs on all 64 lanes, not under `pos < last_c`: a VALU instruction costs the same whatever
@@ -511,8 +512,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                     const float inv_cd = e.inv_depth;  // = p'.z on the fast path: no reciprocal
                     const float m_d = fmaf(-dmd_k, inv_cd, mscale);
                     const float dmd_dd = dmd_k * inv_cd * inv_cd;
-                    float dL_dz = 0.0f;
-                    if (pos < tile_max_median) { const float2 md = s_med[q * 64 + lane]; dL_dz = (pos + 1 == __float_as_uint(md.x)) ? md.y : 0.0f; }  // scalar branch
+                    float dL_dz = (pos + 1 == __float_as_uint(md.x)) ? md.y : 0.0f;
                     const float dL_dweight = fmaf(m_d, fmaf(m_d, cst.x, -cst.y), cst.z);
                     const float dwt = dL_dweight - x.last_dL_dT;
                     dL_dalpha += dwt;
