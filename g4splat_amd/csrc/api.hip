@@ -207,7 +207,7 @@ extern "C" int g4s_rasterizer_layout(int P, int R, int width, int height, g4s_la
     const int passes = (tile_bits + 7) / 8;
     out->rec = g.rec;
     out->clamped = g.clamped;
-    out->depth_sorted = g.vals_b;  // packed into the *_b arrays, four passes -> back in the first buffer
+    out->depth_sorted = g.vals_b;  // wherever the sort starts and however many passes it takes (g4s_rasterizer_forward)
     out->tiles_touched = g.tiles_touched;
     out->geom_bytes = g.bytes;
     out->entries = (passes & 1) ? b.ent_b : b.ent_a;
@@ -311,10 +311,19 @@ static int rasterizer_forward_impl(
         pa.no_fastpath = opt(OPT_NO_FASTPATH) != 0;
         pa.rec = rec; pa.clamped = (uint8_t*)(geom + GL.clamped); pa.tiles_touched = tiles_touched; pa.radii = radii;
         pa.tight_rect = (uint2*)(geom + GL.tight_rect);
-        pa.depth_keys = keys_a;
+        // The depth sort ping-pongs between the a and the b arrays and its result is to land in vals_b whatever the
+        // number of passes (g4s_rasterizer_layout().depth_sorted): three passes (the regular forward) start in the a
+        // arrays, four (presized) in the b arrays; the preprocess writes the unpacked keys into the other key array.
+        uint32_t* const k_first = presized ? keys_b : keys_a;
+        uint32_t* const k_other = presized ? keys_a : keys_b;
+        uint32_t* const v_first = presized ? vals_b : vals_a;
+        uint32_t* const v_other = presized ? vals_a : vals_b;
+        pa.depth_keys = k_other;
         pa.ref_block_sums = (uint32_t*)(geom + GL.ref_block_sums);
         pa.idx_block_sums = (uint32_t*)(geom + GL.idx_block_sums);
         pa.vis_block_sums = (uint32_t*)(geom + GL.vis_block_sums);
+        pa.key_min_blocks = (uint32_t*)(geom + GL.key_min_blocks);
+        pa.key_max_blocks = (uint32_t*)(geom + GL.key_max_blocks);
         { ProfScope ps(PF_PREPROCESS_FWD, stream); launch_preprocess_fwd(pa, stream); }
         CHECK_LAUNCH("preprocess_fwd");
 
@@ -336,7 +345,7 @@ static int rasterizer_forward_impl(
         { ProfScope ps(PF_COUNT_SCAN, stream);
           launch_scan_totals(pa.idx_block_sums, idx_block_offs, pa.ref_block_sums, pa.vis_block_sums, vis_block_offs,
                              d_total, GL.nblocks, ranges, tiles * 2, stream, presized ? (uint32_t)capacity : 0xFFFFFFFFu,
-                             h_total_dev, presized ? status_dev : nullptr); }
+                             h_total_dev, presized ? status_dev : nullptr, pa.key_min_blocks, pa.key_max_blocks); }
         CHECK_LAUNCH("scan totals");
         if (!presized) {
             HIP_TRY(hipEventRecord(totals_ready, stream));  // (the kernel above stored the three counts in host memory)
@@ -348,24 +357,21 @@ static int rasterizer_forward_impl(
         // device, their launches sized for P.  The GPU therefore has ~0.1 ms of work queued while the host reads the
         // totals back, sizes the binning chunk and issues the rest: the read-back no longer drains the queue.
         const uint32_t* d_V = d_total + 2;
-        const uint32_t* gidx_sorted;
-        uint32_t* rank_local;
+        const uint32_t* d_key_min = d_total + 5;  // smallest depth key of the frame (the totals scan)
+        uint32_t* sort_hist = (uint32_t*)(geom + GL.hist);
+        uint32_t* sort_bins = (uint32_t*)(geom + GL.bin_total);
+        int cur;
         {   // depth order of the emitting Gaussians (stable => ties by ascending index): pack, then sort
             ProfScope ps(PF_DEPTH_SORT, stream);
-            launch_slots_and_compact(P, tiles_touched, idx_block_offs, rec, keys_a, vis_block_offs, keys_b, vals_b,
+            launch_slots_and_compact(P, tiles_touched, idx_block_offs, rec, k_other, vis_block_offs, k_first, v_first,
                                      GL.nblocks, stream);
-            const int cur = radix_sort_u32_pairs(keys_b, keys_a, vals_b, vals_a, P, (uint32_t*)(geom + GL.hist),
-                                                 (uint32_t*)(geom + GL.bin_total), stream, d_V);
-            gidx_sorted = cur ? vals_a : vals_b;
-            rank_local = cur ? keys_b : keys_a;  // the key array the sort no longer needs
+            // three passes over the low 27 bits of (key - smallest key): the whole sort unless the frame's depths span a
+            // ratio of 2^16 or more, which the host learns with the totals below.  Presized (no read-back): four passes.
+            cur = presized ? radix_sort_u32_pairs(k_first, k_other, v_first, v_other, P, sort_hist, sort_bins, stream, d_V)
+                           : radix_sort_depth_low(k_first, k_other, v_first, v_other, P, sort_hist, sort_bins, stream, d_V,
+                                                  d_key_min);
         }
         CHECK_LAUNCH("depth sort");
-        {
-            ProfScope ps(PF_COUNT_SCAN, stream);
-            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, rank_local, d_total + 8, GL.nblocks,
-                              stream, d_V);
-        }
-        CHECK_LAUNCH("count scan");
 
         int R_binned, V_emit, nblocks_v;
         const uint32_t* d_counts = nullptr;   // presized: (V, min(binned, capacity)) on the device
@@ -382,6 +388,14 @@ static int rasterizer_forward_impl(
             R_binned = (int)h_total[0];
             V_emit = (int)h_total[2];
             nblocks_v = (V_emit + 255) / 256;
+            if (V_emit > 0 && ((uint64_t)h_total[4] - h_total[3]) >> DEPTH_SORT_LOW_BITS) {  // a frame that deep: the bits above
+                ProfScope ps(PF_DEPTH_SORT, stream);
+                cur = radix_sort_depth_top(k_first, k_other, v_first, v_other, P, cur, sort_hist, sort_bins, stream, d_V,
+                                           d_key_min);
+                CHECK_LAUNCH("depth sort, upper bits");
+                // (a fourth pass: the order is in vals_a now -- back to where everything else expects it)
+                HIP_TRY(hipMemcpyAsync(vals_b, vals_a, (size_t)V_emit * 4, hipMemcpyDeviceToDevice, stream));
+            }
         } else {
             // no read-back: every launch below is sized for the capacity and reads the counts on the device
             R = capacity;  // what the layouts (here and in the backward) are computed from
@@ -391,6 +405,16 @@ static int rasterizer_forward_impl(
             d_counts = d_total + 2;
             d_nbinned = d_total + 3;
         }
+
+        (void)cur;
+        const uint32_t* gidx_sorted = vals_b;
+        uint32_t* rank_local = keys_a;  // (neither key array is needed after the sort)
+        {
+            ProfScope ps(PF_COUNT_SCAN, stream);
+            launch_count_scan(P, gidx_sorted, tiles_touched, block_sums, block_offs, rank_local, d_total + 8, GL.nblocks,
+                              stream, d_V);
+        }
+        CHECK_LAUNCH("count scan");
 
         const BinLayout BL = bin_layout((size_t)R);
         char* bin = binning_buffer(binning_ctx, BL.bytes);

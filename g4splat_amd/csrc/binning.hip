@@ -32,11 +32,21 @@ namespace g4s {
 // every key straight to its destination (the first design: one wave per chunk, 64 scattered 8-byte stores per
 // step) left the sort bound by partial-line writes: 0.043 ms per pass over 4.4 M instances, against 0.022 now.
 
-template <typename K, int ITEMS>
+// BITS = digit width of the kernels' tables: 8 (256 rows; a pass may use fewer bits through `mask`) or 9 (512 rows, two
+// digits per thread where a thread owns a digit: the three-pass depth sort below).  key_base (may be NULL): a device
+// word subtracted from every key before its digit is taken.
+template <typename K>
+__device__ __forceinline__ uint32_t radix_digit(K key, uint32_t base, int shift, uint32_t mask) {
+    return (uint32_t)((K)(key - (K)base) >> shift) & mask;
+}
+
+template <typename K, int ITEMS, int BITS>
 __global__ void __launch_bounds__(256) radix_hist_kernel(const K* __restrict__ keys, int n, int shift, uint32_t mask,
                                                          uint32_t* __restrict__ hist, int nblocks,
-                                                         const uint32_t* __restrict__ d_n) {
-    __shared__ uint32_t h[256];
+                                                         const uint32_t* __restrict__ d_n,
+                                                         const uint32_t* __restrict__ key_base) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t h[BINS];
     constexpr int TK = 256 * ITEMS;
     const int block = (int)blockIdx.x;
     if (d_n != nullptr) {  // the key count only lives on the device: the grid is sized for the largest possible n
@@ -44,8 +54,10 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const K* __restrict__ k
         nblocks = (n + TK - 1) / TK;
         if (block >= nblocks) return;
     }
+    const uint32_t base = key_base != nullptr ? *key_base : 0u;
     const int t = (int)threadIdx.x;
-    h[t] = 0;
+#pragma unroll
+    for (int j = 0; j < BINS / 256; j++) h[t + 256 * j] = 0;
     __syncthreads();
     const int begin = block * TK;
     const int end = imin_(n, begin + TK);
@@ -57,9 +69,10 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const K* __restrict__ k
     }
 #pragma unroll
     for (int u = 0; u < ITEMS; u++)
-        if (begin + 256 * u + t < end) atomicAdd(&h[(uint32_t)(k[u] >> shift) & mask], 1u);
+        if (begin + 256 * u + t < end) atomicAdd(&h[radix_digit(k[u], base, shift, mask)], 1u);
     __syncthreads();
-    hist[(size_t)t * nblocks + block] = h[t];
+#pragma unroll
+    for (int j = 0; j < BINS / 256; j++) hist[(size_t)(t + 256 * j) * nblocks + block] = h[t + 256 * j];
 }
 
 // One block per digit row: exclusive scan of the row in place, row total to bin_total[row].
@@ -85,16 +98,18 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
     if (t == 0) bin_total[blockIdx.x] = total;
 }
 
-template <typename K, bool HAS_VAL, int ITEMS>
+template <typename K, bool HAS_VAL, int ITEMS, int BITS>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                             const uint32_t* __restrict__ vals_in,
                                                             uint32_t* __restrict__ vals_out, int n, int shift, uint32_t mask,
                                                             const uint32_t* __restrict__ hist,
                                                             const uint32_t* __restrict__ bin_total, int nblocks,
-                                                            const uint32_t* __restrict__ d_n) {
+                                                            const uint32_t* __restrict__ d_n,
+                                                            const uint32_t* __restrict__ key_base) {
     constexpr int TK = 256 * ITEMS;
-    __shared__ uint32_t s_cnt[4][256];  // wave-private digit counters, then: first local slot of (wave, digit)
-    __shared__ uint32_t s_gbase[256];   // global position of local slot 0 of digit d, i.e. dst = s_gbase[d] + slot
+    constexpr int BINS = 1 << BITS, PER = BINS / 256;  // digits a thread owns in the offsets step: PER * t .. PER * t + PER - 1
+    __shared__ uint32_t s_cnt[4][BINS];  // wave-private digit counters, then: first local slot of (wave, digit)
+    __shared__ uint32_t s_gbase[BINS];   // global position of local slot 0 of digit d, i.e. dst = s_gbase[d] + slot
     __shared__ uint32_t sm4[4];
     __shared__ K s_keys[TK];
     __shared__ uint32_t s_vals[HAS_VAL ? TK : 1];
@@ -104,6 +119,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
         nblocks = (n + TK - 1) / TK;
         if (block >= nblocks) return;
     }
+    const uint32_t base = key_base != nullptr ? *key_base : 0u;
     const int t = (int)threadIdx.x, w = t >> 6, lane = t & 63;
     const int begin = block * TK;
     const int end = imin_(n, begin + TK);
@@ -118,17 +134,19 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
         val[u] = HAS_VAL ? vals_in[ic] : 0u;
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) s_cnt[j][t] = 0;
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < PER; i++) s_cnt[j][t + 256 * i] = 0;
     __syncthreads();
     const uint64_t below = lanes_below_mask();
     uint32_t lrank[ITEMS];  // rank of the key among the keys of its wave with the same digit
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         const bool valid = wbegin + 64 * u + lane < end;
-        const uint32_t d = (uint32_t)(key[u] >> shift) & mask;
-        uint64_t m = __ballot(valid);  // match-any over the 8 digit bits
+        const uint32_t d = radix_digit(key[u], base, shift, mask);
+        uint64_t m = __ballot(valid);  // match-any over the digit bits
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const uint64_t bal = __ballot(bit);
             m &= bit ? bal : ~bal;
@@ -140,22 +158,39 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
         lrank[u] = old + rank;
     }
     __syncthreads();
-    {   // digit t: block-local start, first slot of every wave's share, global base of this block's run
-        const uint32_t c0 = s_cnt[0][t], c1 = s_cnt[1][t], c2 = s_cnt[2][t], c3 = s_cnt[3][t];
+    {   // digits PER * t ..: block-local start, first slot of every wave's share, global base of this block's run
+        uint32_t c[PER][4], own[PER], tot[PER], own_sum = 0, tot_sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int d = PER * t + i;
+#pragma unroll
+            for (int j = 0; j < 4; j++) c[i][j] = s_cnt[j][d];
+            own[i] = (c[i][0] + c[i][1]) + (c[i][2] + c[i][3]);
+            tot[i] = bin_total[d];
+            own_sum += own[i];
+            tot_sum += tot[i];
+        }
         uint32_t total;
-        const uint32_t dstart = block256_excl_scan_u32(c0 + c1 + c2 + c3, sm4, &total);
-        const uint32_t gdigit = block256_excl_scan_u32(bin_total[t], sm4, &total);  // first position of digit t overall
-        s_cnt[0][t] = dstart;
-        s_cnt[1][t] = dstart + c0;
-        s_cnt[2][t] = dstart + c0 + c1;
-        s_cnt[3][t] = dstart + c0 + c1 + c2;
-        s_gbase[t] = gdigit + hist[(size_t)t * nblocks + block] - dstart;
+        uint32_t dstart = block256_excl_scan_u32(own_sum, sm4, &total);
+        uint32_t gdigit = block256_excl_scan_u32(tot_sum, sm4, &total);  // first position of digit PER * t overall
+        // (the second scan's barriers: every thread has read its counters before anybody overwrites them)
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int d = PER * t + i;
+            s_cnt[0][d] = dstart;
+            s_cnt[1][d] = dstart + c[i][0];
+            s_cnt[2][d] = dstart + c[i][0] + c[i][1];
+            s_cnt[3][d] = dstart + c[i][0] + c[i][1] + c[i][2];
+            s_gbase[d] = gdigit + hist[(size_t)d * nblocks + block] - dstart;
+            dstart += own[i];
+            gdigit += tot[i];
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < ITEMS; u++) {
         if (wbegin + 64 * u + lane < end) {
-            const uint32_t d = (uint32_t)(key[u] >> shift) & mask;
+            const uint32_t d = radix_digit(key[u], base, shift, mask);
             const uint32_t slot = s_cnt[w][d] + lrank[u];
             s_keys[slot] = key[u];
             if (HAS_VAL) s_vals[slot] = val[u];
@@ -168,7 +203,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
         const int slot = 256 * u + t;
         if (slot < nvalid) {
             const K k = s_keys[slot];
-            const uint32_t dst = s_gbase[(uint32_t)(k >> shift) & mask] + (uint32_t)slot;
+            const uint32_t dst = s_gbase[radix_digit(k, base, shift, mask)] + (uint32_t)slot;
             keys_out[dst] = k;
             if (HAS_VAL) vals_out[dst] = s_vals[slot];
         }
@@ -177,16 +212,18 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* __restrict_
 
 // d_n == nullptr: n keys (host-known).  Otherwise n is read from *d_n by the kernels and only bounds the grid
 // (n_max >= *d_n): the launches can be queued before the host knows the count.
-template <typename K, bool HAS_VAL, int ITEMS>
+template <typename K, bool HAS_VAL, int ITEMS, int BITS = 8>
 static void radix_pass(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int n, int shift, int bits, uint32_t* hist,
-                       uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr) {
+                       uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr,
+                       const uint32_t* key_base = nullptr) {
     constexpr int TK = 256 * ITEMS;
     const int nblocks = (n + TK - 1) / TK;
-    const uint32_t mask = (1u << bits) - 1u;  // digit width <= 8 bits (256 histogram rows; rows above the mask stay empty)
-    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS>), dim3(nblocks), dim3(256), 0, s, kin, n, shift, mask, hist, nblocks, d_n);
-    hipLaunchKernelGGL(radix_scan_kernel<TK>, dim3(256), dim3(256), 0, s, hist, nblocks, bin_total, d_n);
-    hipLaunchKernelGGL((radix_scatter_kernel<K, HAS_VAL, ITEMS>), dim3(nblocks), dim3(256), 0, s, kin, kout, vin, vout, n,
-                       shift, mask, hist, bin_total, nblocks, d_n);
+    const uint32_t mask = (1u << bits) - 1u;  // digit width <= BITS (rows above the mask stay empty)
+    hipLaunchKernelGGL((radix_hist_kernel<K, ITEMS, BITS>), dim3(nblocks), dim3(256), 0, s, kin, n, shift, mask, hist, nblocks,
+                       d_n, key_base);
+    hipLaunchKernelGGL(radix_scan_kernel<TK>, dim3(1 << BITS), dim3(256), 0, s, hist, nblocks, bin_total, d_n);
+    hipLaunchKernelGGL((radix_scatter_kernel<K, HAS_VAL, ITEMS, BITS>), dim3(nblocks), dim3(256), 0, s, kin, kout, vin, vout,
+                       n, shift, mask, hist, bin_total, nblocks, d_n, key_base);
 }
 
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
@@ -201,6 +238,37 @@ int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, u
         cur ^= 1;
     }
     return cur;
+}
+
+// The depth sort of a frame: keys are the float bits of positive depths, and the keys of one frame span far fewer than
+// 32 bits -- a depth ratio of 2^16 between the farthest and the nearest emitting Gaussian is 16 exponent steps = 2^27
+// key values.  Sorting (key - smallest key), which orders exactly as the keys do, therefore takes THREE passes of
+// 9 bits (bits 0..26 of the difference) for every frame whose range is below 2^27, a launch-bound 3 x 3 kernels
+// instead of 4 x 3.  The range is only known on the device when the passes are queued (key_min: a device word); the
+// host learns it with the frame's totals and queues radix_sort_depth_top() for the remaining five bits if a frame
+// ever needs it.  Returns the ping-pong index of the result, as radix_sort_u32_pairs does.
+int radix_sort_depth_low(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n, uint32_t* hist,
+                         uint32_t* bin_total, hipStream_t s, const uint32_t* d_n, const uint32_t* key_min) {
+    if (n <= 0) return 0;
+    int cur = 0;
+    for (int shift = 0; shift < DEPTH_SORT_LOW_BITS; shift += 9) {
+        if (cur == 0)
+            radix_pass<uint32_t, true, SORT_ITEMS_U32, 9>(keys_a, keys_b, vals_a, vals_b, n, shift, 9, hist, bin_total, s, d_n, key_min);
+        else
+            radix_pass<uint32_t, true, SORT_ITEMS_U32, 9>(keys_b, keys_a, vals_b, vals_a, n, shift, 9, hist, bin_total, s, d_n, key_min);
+        cur ^= 1;
+    }
+    return cur;
+}
+// bits 27..31 of (key - key_min): from buffer `cur` into the other one; returns the new index
+int radix_sort_depth_top(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n, int cur,
+                         uint32_t* hist, uint32_t* bin_total, hipStream_t s, const uint32_t* d_n, const uint32_t* key_min) {
+    if (n <= 0) return cur;
+    if (cur == 0)
+        radix_pass<uint32_t, true, SORT_ITEMS_U32>(keys_a, keys_b, vals_a, vals_b, n, DEPTH_SORT_LOW_BITS, 32 - DEPTH_SORT_LOW_BITS, hist, bin_total, s, d_n, key_min);
+    else
+        radix_pass<uint32_t, true, SORT_ITEMS_U32>(keys_b, keys_a, vals_b, vals_a, n, DEPTH_SORT_LOW_BITS, 32 - DEPTH_SORT_LOW_BITS, hist, bin_total, s, d_n, key_min);
+    return cur ^ 1;
 }
 
 // Stable partition on bits [begin_bit, end_bit): ceil(bits / 8) passes of EQUAL width (13 tile bits -> 7 + 6 rather than
@@ -257,24 +325,36 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
                                                                uint32_t* __restrict__ zero_ptr, int zero_words,
                                                                const uint32_t* __restrict__ d_n, uint32_t capacity,
                                                                uint32_t* __restrict__ host_out,
-                                                               uint32_t* __restrict__ status_out) {
-    __shared__ uint32_t wa[16], wb[16], wr[16];
+                                                               uint32_t* __restrict__ status_out,
+                                                               const uint32_t* __restrict__ kmin_blocks,
+                                                               const uint32_t* __restrict__ kmax_blocks) {
+    __shared__ uint32_t wa[16], wb[16], wr[16], wlo[16], whi[16];
     const int t = (int)threadIdx.x;
     for (int i = t; i < zero_words; i += 1024) zero_ptr[i] = 0u;
     if (d_n != nullptr) nblocks = (int)((*d_n + 255u) / 256u);  // blocks of a device-side element count
     const int seg = (nblocks + 1023) / 1024;
     const int b = imin_(nblocks, t * seg), e = imin_(nblocks, b + seg);
-    uint32_t sa = 0, sb = 0, sr = 0;
+    uint32_t sa = 0, sb = 0, sr = 0, klo = 0xFFFFFFFFu, khi = 0u;
     for (int i = b; i < e; i++) {
         sa += a_sums[i];
         if (b_sums) sb += b_sums[i];
         if (ref_sums) sr += ref_sums[i];
+        if (kmin_blocks) {  // range of the frame's depth keys
+            klo = min(klo, kmin_blocks[i]);
+            khi = max(khi, kmax_blocks[i]);
+        }
+    }
+    if (kmin_blocks) {
+        klo = ~wave_max_u32_full_wave(~klo);
+        khi = wave_max_u32_full_wave(khi);
     }
     const uint32_t ia = wave_incl_scan_u32(sa), ib = wave_incl_scan_u32(sb), ir = wave_incl_scan_u32(sr);
     if ((t & 63) == 63) {
         wa[t >> 6] = ia;
         wb[t >> 6] = ib;
         wr[t >> 6] = ir;
+        wlo[t >> 6] = klo;
+        whi[t >> 6] = khi;
     }
     __syncthreads();
     uint32_t base_a = 0, base_b = 0, all_a = 0, all_b = 0, all_r = 0;
@@ -293,6 +373,14 @@ __global__ void __launch_bounds__(1024) scan_block_sums_kernel(int nblocks, cons
     if (t == 0) {
         total_a[0] = all_a;
         total_a[1] = all_r;
+        if (kmin_blocks) {  // total[5] = smallest depth key of the frame (the sort subtracts it), total[6] = largest
+            uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+            for (int w = 0; w < 16; w++) { lo = min(lo, wlo[w]); hi = max(hi, whi[w]); }
+            if (lo > hi) lo = hi = 0u;  // (no emitting Gaussian)
+            total_a[5] = lo;
+            total_a[6] = hi;
+            if (host_out != nullptr) { host_out[3] = lo; host_out[4] = hi; }
+        }
         if (b_sums) {
             total_b[0] = all_b;
             // (presized forward) total_b[1] = instances that fit the caller's binning capacity, total_b[2] = overflow flag
@@ -321,7 +409,8 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
                        block_sums, rank_local, d_n);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, block_sums, block_offs,
                        (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, total, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, 0, d_n, 0xFFFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       (uint32_t*)nullptr, 0, d_n, 0xFFFFFFFFu, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 }
 
 // Load-balanced expansion, partitioned by OUTPUT: a block owns EMIT_SLOTS consecutive instance slots, whatever
@@ -458,12 +547,12 @@ void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
                         uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity, uint32_t* host_out,
-                        uint32_t* status_out) {
+                        uint32_t* status_out, const uint32_t* key_min_blocks, const uint32_t* key_max_blocks) {
     // total[0] = instances binned, total[1] = the reference's num_rendered, total[2] = emitting Gaussians,
     // total[3] = min(total[0], capacity), total[4] = 1 if total[0] > capacity
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblocks, idx_block_sums, idx_block_offs,
                        vis_block_sums, vis_block_offs, ref_block_sums, total, total + 2, zero_ptr, zero_words,
-                       (const uint32_t*)nullptr, capacity, host_out, status_out);
+                       (const uint32_t*)nullptr, capacity, host_out, status_out, key_min_blocks, key_max_blocks);
 }
 
 void launch_emit(int V, uint32_t R_b, int tiles_x, const uint32_t* gidx_sorted, const uint32_t* block_offs,

@@ -176,6 +176,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     }
     return v;
 }
+// The same for a wave whose 64 lanes are all active: the DPP ladder of wave_sum_to_lane63 with max (lanes a row mask
+// leaves out read 0, the identity of an unsigned max), six VALU instructions instead of six trips through the LDS crossbar.
+__device__ __forceinline__ uint32_t wave_max_u32_full_wave(uint32_t v) {
+    v = max(v, dpp_u32<0xB1>(v));
+    v = max(v, dpp_u32<0x4E>(v));
+    v = max(v, dpp_u32<0x124>(v));
+    v = max(v, dpp_u32<0x128>(v));
+    v = max(v, dpp_u32<0x142, 0xA>(v));
+    v = max(v, dpp_u32<0x143, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 // Inclusive prefix sum over the wave (lane i gets sum of lanes 0..i).
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {

@@ -59,6 +59,9 @@ constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 constexpr int SORT_ITEMS_U32 = G4S_SORT_ITEMS_U32;  // depth sort of the emitting Gaussians (32-bit keys + index)
 constexpr int SORT_ITEMS_U64 = G4S_SORT_ITEMS_U64;  // tile partition of the packed instances
 inline size_t sort_blocks(size_t n, int items) { return (n + (size_t)256 * items - 1) / ((size_t)256 * items); }
+// The depth sort takes three 9-bit passes over (key - smallest key of the frame) and a fourth one over the bits above
+// only for a frame whose keys span 2^27 values or more (binning.hip: radix_sort_depth_low / _top).
+constexpr int DEPTH_SORT_LOW_BITS = 27;
 // Packed instance: bits 63..32 tile id, 31..0 Gaussian index -- the reference's key without the depth bits
 // (rasterizer_impl.cu:102-103 keeps the tile id in the upper word too), so any frame the reference can render fits.
 // Both fields sit on a 32-bit boundary on purpose: hipcc (ROCm 7.2) narrows "(e >> 24) & 0xFFFFFF" to a 3-byte load
@@ -83,7 +86,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // (the reference's GeometryState/BinningState/ImageState, rasterizer_impl.h:21-73).
 struct GeomLayout {
     size_t rec, clamped, tiles_touched, tight_rect, internal_radii, keys_a, keys_b, vals_a, vals_b, hist, bin_total,
-        block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, vis_block_sums, vis_block_offs, total, bytes;
+        key_min_blocks, key_max_blocks, block_sums, block_offs, ref_block_sums, idx_block_sums, idx_block_offs, vis_block_sums, vis_block_offs, total, bytes;
     int nblocks;   // 256-wide blocks over P
 };
 struct BinLayout {
@@ -108,8 +111,10 @@ inline GeomLayout geom_layout(size_t P) {
     L.vals_a = take(P * 4);
     L.vals_b = take(P * 4);
     // the depth sort runs over the emitting Gaussians only (n <= P): capacity for n = P
-    L.hist = take((size_t)256 * (sort_blocks(P, SORT_ITEMS_U32) + 1) * 4);
-    L.bin_total = take(256 * 4);
+    L.hist = take((size_t)512 * (sort_blocks(P, SORT_ITEMS_U32) + 1) * 4);  // (9-bit digits: 512 rows)
+    L.bin_total = take(512 * 4);
+    L.key_min_blocks = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
+    L.key_max_blocks = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.block_offs = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
     L.ref_block_sums = take((size_t)(L.nblocks ? L.nblocks : 1) * 4);
@@ -160,6 +165,8 @@ struct PreprocessArgs {
     uint32_t* ref_block_sums;  // per 256-Gaussian block: sum of the reference's tiles_touched (3-sigma rect)
     uint32_t* idx_block_sums;  // per 256-Gaussian block (index order): sum of the binned tile counts
     uint32_t* vis_block_sums;  // per 256-Gaussian block: number of Gaussians that emit at least one instance
+    uint32_t* key_min_blocks;  // per 256-Gaussian block: smallest / largest depth key among them (0xFFFFFFFF / 0 if none)
+    uint32_t* key_max_blocks;
     const float *means3D, *scales, *rotations, *opacities, *shs, *transMat_precomp, *colors_precomp;
     const float *viewmatrix, *projmatrix, *cam_pos;
     float scale_modifier;
@@ -181,6 +188,12 @@ void launch_mark_visible(int P, const float* means3D, const float* viewmatrix, u
 // d_n != nullptr: the count is read from *d_n on the device, `n` (>= *d_n) only sizes the launches.
 int radix_sort_u32_pairs(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n,
                          uint32_t* hist, uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr);
+// The depth sort: three 9-bit passes over bits [0, DEPTH_SORT_LOW_BITS) of (key - *key_min) -- complete for a frame whose
+// keys span less than 2^27 values --, and the pass over the bits above for one that spans more (from buffer `cur`).
+int radix_sort_depth_low(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n, uint32_t* hist,
+                         uint32_t* bin_total, hipStream_t s, const uint32_t* d_n, const uint32_t* key_min);
+int radix_sort_depth_top(uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int n, int cur,
+                         uint32_t* hist, uint32_t* bin_total, hipStream_t s, const uint32_t* d_n, const uint32_t* key_min);
 // 64-bit keys-only over bits [begin_bit, end_bit).
 int radix_sort_u64_keys(uint64_t* a, uint64_t* b, int n, int begin_bit, int end_bit, uint32_t* hist,
                         uint32_t* bin_total, hipStream_t s, const uint32_t* d_n = nullptr);
@@ -196,7 +209,8 @@ void launch_count_scan(int P, const uint32_t* gidx_sorted, const uint32_t* tiles
 void launch_scan_totals(const uint32_t* idx_block_sums, uint32_t* idx_block_offs, const uint32_t* ref_block_sums,
                         const uint32_t* vis_block_sums, uint32_t* vis_block_offs, uint32_t* total, int nblocks,
                         uint32_t* zero_ptr, int zero_words, hipStream_t s, uint32_t capacity = 0xFFFFFFFFu,
-                        uint32_t* host_out = nullptr, uint32_t* status_out = nullptr);
+                        uint32_t* host_out = nullptr, uint32_t* status_out = nullptr,
+                        const uint32_t* key_min_blocks = nullptr, const uint32_t* key_max_blocks = nullptr);
 // Index-order pass: gradient-record slots (rec[idx].inst_off = exclusive scan of tiles_touched over idx) and the
 // stable compaction of the emitting Gaussians' (depth key, index) pairs.
 void launch_slots_and_compact(int P, const uint32_t* tiles_touched, const uint32_t* idx_block_offs, float* rec,

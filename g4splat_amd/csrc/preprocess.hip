@@ -501,14 +501,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
     }
     // num_rendered of the reference = sum of its tiles_touched: per-block partial, summed by the
     // count-scan kernel (a same-address atomic per wave serialises at ~90 atomics/us on this part)
-    __shared__ uint32_t s_ref[4], s_tight[4], s_vis[4];
+    __shared__ uint32_t s_ref[4], s_tight[4], s_vis[4], s_kmin[4], s_kmax[4];
     const uint32_t wsum = wave_sum_u32(touched_ref);
     const uint32_t tsum = wave_sum_u32(touched);
     const uint32_t vsum = (uint32_t)__popcll(__ballot(touched > 0));
+    // range of the depth keys that take part in the sort (binning.hip: three passes over key - smallest key)
+    const uint32_t kmax = wave_max_u32_full_wave(touched > 0 ? key : 0u);
+    const uint32_t kmin = ~wave_max_u32_full_wave(touched > 0 ? ~key : 0u);
     if (lane_id() == 0) {
         s_ref[threadIdx.x >> 6] = wsum;
         s_tight[threadIdx.x >> 6] = tsum;
         s_vis[threadIdx.x >> 6] = vsum;
+        s_kmin[threadIdx.x >> 6] = kmin;
+        s_kmax[threadIdx.x >> 6] = kmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -517,6 +522,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         a.idx_block_sums[blockIdx.x] = (s_tight[0] + s_tight[1]) + (s_tight[2] + s_tight[3]);
         // Gaussians of this block that emit instances: base of their slots in the compacted depth-sort input
         a.vis_block_sums[blockIdx.x] = (s_vis[0] + s_vis[1]) + (s_vis[2] + s_vis[3]);
+        a.key_min_blocks[blockIdx.x] = min(min(s_kmin[0], s_kmin[1]), min(s_kmin[2], s_kmin[3]));
+        a.key_max_blocks[blockIdx.x] = max(max(s_kmax[0], s_kmax[1]), max(s_kmax[2], s_kmax[3]));
     }
 }
 

@@ -94,6 +94,38 @@ def test_stages_match_oracle(hip_lib, oracle_mod):
     assert_parity(h, o, inp, oracle_mod)
 
 
+@pytest.mark.parametrize("stretch", [1.0, 3.0e5])
+def test_depth_order_of_a_frame_whose_keys_span_more_than_the_three_pass_sort_covers(hip_lib, oracle_mod, stretch):
+    """The depth sort takes three 9-bit passes over (key - smallest key) and a fourth one only for a frame whose keys span
+    2^27 values or more, i.e. a depth ratio of 2^16 (csrc/binning.hip: radix_sort_depth_low / _top).  stretch = 3e5 moves
+    every third Gaussian that far out along its ray (scaled with it: the same footprint), so the frame needs the fourth
+    pass; stretch = 1 is the same frame without it."""
+    inp = scene_inputs(P=6000, W=208, H=144, seed=23, D=1, scale_mul=1.5)
+    far = np.arange(6000) % 3 == 0
+    cam = np.asarray(inp["campos"], np.float64)
+    m = inp["means3D"].astype(np.float64)
+    m[far] = cam + stretch * (m[far] - cam)
+    inp["means3D"] = m.astype(np.float32)
+    sc = inp["scales"].copy()
+    sc[far] *= np.float32(stretch)
+    inp["scales"] = sc
+    g = cotangents(144, 208, seed=5)
+    o = run_oracle(oracle_mod, inp, g)
+    h = run_hip(inp, g)
+    st = hip_state(h, inp)
+    emit = st["tiles_touched"] > 0
+    keys = o["oracle"].state("depths").view(np.uint32)
+    span = int(keys[emit].max()) - int(keys[emit].min())
+    assert (span >= 1 << 27) == (stretch > 1.0), span  # the case the parameter names
+    assert (emit & far).sum() > 200 and (emit & ~far).sum() > 200
+    want = np.nonzero(emit)[0][np.argsort(keys[emit], kind="stable")].astype(np.uint32)
+    np.testing.assert_array_equal(st["depth_sorted"][:len(want)], want)
+    kept, total = check_lists_against_oracle(st, o["oracle"], oracle_mod)
+    assert kept == int(st["tiles_touched"].sum()) and total == o["R"]
+    # (depths of 1e5 in the depth channels: the 1e-4 bar relative to the magnitude of what it is applied to)
+    assert_parity(h, o, inp, oracle_mod, scale_aware=stretch > 1.0)
+
+
 @pytest.mark.parametrize("D", [0, 1, 2, 3])
 def test_config1_forward_backward(hip_lib, oracle_mod, D):
     """BASELINE config 1: 10k random Gaussians, one 256x256 pinhole camera."""
