@@ -444,9 +444,12 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
             const int j = (int)__builtin_ctzll(todo);
             todo &= ~(1ull << j);  // (one s_andn2_b64 instead of the three instructions of `todo & (todo - 1)`, see the forward)
             const uint32_t qm = (uint32_t)__builtin_amdgcn_readlane((int)qmask, j);  // wave-uniform
-            const bool nolp = (nolp_mask >> j) & 1ull;                               // scalar
+            // bit j of the mask as a 0 / 1 word in an SGPR, taken by hand: from `(nolp_mask >> j) & 1` hipcc builds a lane
+            // mask, turns it into a 0 / 1 VGPR and compares that again (v_cndmask + v_cmp + five scalar instructions per entry)
+            uint32_t nolp_s, general;
+            asm volatile("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(nolp_s) : "s"(nolp_mask), "s"(j) : "scc");
             // == !nolp, in an SGPR and opaque to the optimiser (see the gradient block)
-            const uint32_t general = (uint32_t)__builtin_amdgcn_readfirstlane(nolp ? 0 : 1);
+            asm volatile("s_xor_b32 %0, %1, 1" : "=s"(general) : "s"(nolp_s) : "scc");
             const uint32_t pos = (uint32_t)(hi - 1 - j);  // 0-based list position == backward `contributor`
             const float4 q0 = s_rec[0][j], q1 = s_rec[1][j], q2 = s_rec[2][j], q3 = s_rec[3][j], q4 = s_rec[4][j];
             // the accumulators are plain floats zeroed one by one, and the zero is pinned here: left alone, the
@@ -481,8 +484,12 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                 // eval_pair runs on all 64 lanes, not under `pos < last_c`: a VALU instruction costs the same whatever
                 // EXEC says, and the mask region around it (s_and_saveexec, branch, restore) is pure overhead in a
                 // kernel whose waves are short of issue slots: -3.2 % (profiles/r04_ab_blend_bwd.txt)
-                const bool pass = eval_pair(nolp, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
+                // (the flag re-read behind an empty asm at every use: left to itself hipcc forms ONE `nolp_s == 0` for the
+                // four visits, keeps it as a 0 / 1 VGPR across their branches and compares that again in front of each)
+                asm volatile("" : "+s"(nolp_s));
+                const bool pass = eval_pair(nolp_s, pxf, pyf, q0.x, q0.y, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q1.w, e);
                 const bool act = pass && pos < x.last_c;
+                asm volatile("" : "+s"(nolp_s));  // (again, for the test in the gradient block)
                 // (qhit is exact, so some pixel of the quadrant is active; no wave vote needed)
                 if (act) {
                     const float G = e.G, alpha = e.alpha, c_d = e.depth;
@@ -525,15 +532,15 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
                     const float dL_dG = q1.w * dL_dalpha;  // not gated by the 0.99 clamp (backward.cu:390)
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
 
-                    if (nolp) {  // scalar branch: REC_AFFINE splat (always in3d)
+                    if (nolp_s) {  // scalar branch: REC_AFFINE splat (always in3d)
                         // backward.cu:396-426 in the affine form: G = exp(-|s|^2 / 2), s = p'.xy / p'.z, depth = 1 / p'.z
                         //   dL/dp'.xy = dL/ds / p'.z,   dL/dp'.z = -(s . dL/ds + depth dL/ddepth) / p'.z
                         // and the only thing accumulated for T are the moments S, X, Y of dL/dp' (the reference's dL/dk =
                         // l x dL/dp, dL/dl = dL/dp x k and its 18 accumulations per pixel are linear in the pixel: K8 takes
                         // the cross products once per Gaussian)
-                        const float mGi = (dL_dG * -G) * e.inv_pz;
+                        const float mGi = (dL_dG * -G) * e.depth;  // (e.depth: 1 / p'.z, see eval_pair)
                         const float dpx_ = mGi * e.sx, dpy_ = mGi * e.sy;
-                        const float ndpz = fmaf(dpx_, e.sx, fmaf(dpy_, e.sy, (dL_dz * e.inv_pz) * e.inv_pz));  // -dL/dp'.z (depth = 1 / p'.z)
+                        const float ndpz = fmaf(dpx_, e.sx, fmaf(dpy_, e.sy, (dL_dz * e.depth) * e.depth));  // -dL/dp'.z (depth = 1 / p'.z)
                         acc_add(gt0, dpx_);  // (in place: see acc_fma)
                         acc_add(gt1, dpy_);
                         acc_sub(gt2, ndpz);
@@ -771,9 +778,9 @@ __global__ void __launch_bounds__(256) blend_bwd_hot_kernel(BlendBwdArgs a) {
                     const float dL_dG = q1.w * dL_dalpha;
                     dL_dz = fmaf(w, x.dL_ddepth, dL_dz);
                     if (nolp) {
-                        const float mGi = (dL_dG * -G) * e.inv_pz;
+                        const float mGi = (dL_dG * -G) * e.depth;  // (e.depth: 1 / p'.z, see eval_pair)
                         const float dpx_ = mGi * e.sx, dpy_ = mGi * e.sy;
-                        const float ndpz = fmaf(dpx_, e.sx, fmaf(dpy_, e.sy, (dL_dz * e.inv_pz) * e.inv_pz));
+                        const float ndpz = fmaf(dpx_, e.sx, fmaf(dpy_, e.sy, (dL_dz * e.depth) * e.depth));
                         acc_add(g[6], dpx_); acc_add(g[7], dpy_); acc_sub(g[8], ndpz);
                         acc_fma(g[9], e.dx, dpx_); acc_fma(g[10], e.dx, dpy_); acc_fnma(g[11], e.dx, ndpz);
                         acc_fma(g[12], e.dy, dpx_); acc_fma(g[13], e.dy, dpy_); acc_fnma(g[14], e.dy, ndpz);

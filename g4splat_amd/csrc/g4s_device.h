@@ -390,7 +390,9 @@ __device__ __forceinline__ bool eval_rho_affine(float pxf, float pyf, float cx, 
 // REC_AFFINE; c0..c8 are then A', B', Dc', otherwise Tu, Tv, Tw (record quads 2..4).  The two kinds of splat share
 // everything after p: the general extras sit inside one uniform branch that only refines values the common code has
 // already produced.
-__device__ __forceinline__ bool eval_pair(bool affine, float pxf, float pyf, float cx, float cy, float c0, float c1,
+// (Flag: bool, or a 0 / 1 word the caller keeps in an SGPR)
+template <typename Flag>
+__device__ __forceinline__ bool eval_pair(Flag affine, float pxf, float pyf, float cx, float cy, float c0, float c1,
                                           float c2, float c3, float c4, float c5, float c6, float c7, float c8,
                                           float opa, PairEval& e) {
     // No early exits: the three rejections (p.z == 0, depth < near, alpha < 1/255) are ANDed into the returned
@@ -448,8 +450,10 @@ __device__ __forceinline__ bool eval_pair(bool affine, float pxf, float pyf, flo
         e.inv_depth = __builtin_amdgcn_rcpf(e.depth);
         // forward.cu:378 `if (depth < near_n) continue;` (REC_AFFINE certifies depth >= near wherever the splat can pass)
         ok = ppz != 0.0f && !(e.depth < NEAR_N);
+        // 1 / p.z for the general gradient block.  Set on this path only: an affine splat's 1 / p'.z IS its depth, and a
+        // second name for it that the other arm redefines costs the common arm a register copy at the join.
+        e.inv_pz = inv;
     }
-    e.inv_pz = inv;
     // forward.cu:383-385 `power = -0.5 rho; if (power > 0) continue;` can never fire (rho is a sum of squares),
     // and exp(power) = exp2(rho * (-0.5 log2 e)): scaling by -0.5 is exact, so folding it into the constant
     // rounds exactly like (-0.5f * rho) * log2e.  One v_exp_f32: rho in [0, 11.2] for anything that can pass,
