@@ -421,9 +421,10 @@ __device__ __forceinline__ bool eval_pair(Flag affine, float pxf, float pyf, flo
     e.depth = inv;      // affine: det(T) / p.z with p pre-divided by det(T)
     e.inv_depth = ppz;
     // forward.cu:354 `if (p.z == 0.0) continue;` -- for the affine form: a NORMAL p'.z.  1 / denormal is +-inf here (one
-    // v_rcp_f32), and where p'.x is exactly 0 on the same pixel 0 x inf = NaN would survive fminf(0.99, NaN) as alpha = 0.99;
-    // the reference divides and gets s = 0 there.  (|p'.z| < 1e-38 means a depth beyond 1e38: the horizon of the splat's plane.)
-    bool ok = fabsf(ppz) >= 1.17549435e-38f;
+    // v_rcp_f32): s is then +-inf (rho = inf, G = 0, alpha = 0) or, where p'.x is exactly 0 on the same pixel, 0 x inf = NaN,
+    // which fminf(0.99, NaN) would turn into alpha = 0.99.  Neither needs a test of its own: the alpha test at the end is an
+    // ORDERED compare of opa * G, before the clamp, and rejects 0 and NaN alike -- a v_cmp and an s_and less per visit than
+    // a predicate on p'.z ANDed in.  (|p'.z| < 1e-38 means a depth beyond 1e38: the horizon of the splat's plane.)
     if (__builtin_expect(!affine, 0)) {  // forward.cu:355-378 with (c0..c2) = Tu, (c3..c5) = Tv, (c6..c8) = Tw  (out of line: the common path falls through)
         const float kx = fmaf(pxf, c6, -c0), ky = fmaf(pxf, c7, -c1), kz = fmaf(pxf, c8, -c2);
         const float lx = fmaf(pyf, c6, -c3), ly = fmaf(pyf, c7, -c4), lz = fmaf(pyf, c8, -c5);
@@ -449,7 +450,8 @@ __device__ __forceinline__ bool eval_pair(Flag affine, float pxf, float pyf, flo
         e.depth = e.in3d ? d3 : c8;
         e.inv_depth = __builtin_amdgcn_rcpf(e.depth);
         // forward.cu:378 `if (depth < near_n) continue;` (REC_AFFINE certifies depth >= near wherever the splat can pass)
-        ok = ppz != 0.0f && !(e.depth < NEAR_N);
+        // (the reference's two rejections of this path enter the alpha test the same way: an infinite exponent is G = 0)
+        if (!(ppz != 0.0f && !(e.depth < NEAR_N))) rho = __builtin_inff();
         // 1 / p.z for the general gradient block.  Set on this path only: an affine splat's 1 / p'.z IS its depth, and a
         // second name for it that the other arm redefines costs the common arm a register copy at the join.
         e.inv_pz = inv;
@@ -459,8 +461,11 @@ __device__ __forceinline__ bool eval_pair(Flag affine, float pxf, float pyf, flo
     // rounds exactly like (-0.5f * rho) * log2e.  One v_exp_f32: rho in [0, 11.2] for anything that can pass,
     // error ~3e-7 relative.
     e.G = __builtin_amdgcn_exp2f(rho * (-0.5f * 1.4426950408889634f));
-    e.alpha = fminf(0.99f, opa * e.G);
-    return ok && !(e.alpha < 1.0f / 255.0f);  // forward.cu:391 `if (alpha < 1.0f / 255.0f) continue;`
+    const float a = opa * e.G;
+    // (v_min_f32 by hand: behind the branch on the test below hipcc no longer knows that `a` is a canonical number and
+    // puts a v_max_f32 a, a in front of fminf's v_min)
+    asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(e.alpha) : "v"(a));  // fminf(0.99f, a)
+    return a >= 1.0f / 255.0f;  // forward.cu:391 `if (alpha < 1.0f / 255.0f) continue;` (0.99 > 1 / 255: the clamp never decides it)
 }
 
 }  // namespace g4s
