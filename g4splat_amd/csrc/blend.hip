@@ -340,7 +340,6 @@ struct BwdPixelLite {  // what stays in registers per pixel; the rest of BwdPixe
 };
 __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
     __shared__ float4 s_rec[BLEND_QUADS][BWD1_BATCH];  // the culling quads are not needed here
-    __shared__ uint32_t s_slot[BWD1_BATCH];
     __shared__ float4 s_cst[256];   // per pixel (quadrant * 64 + lane): A2, D2, C2, nTfbg
     __shared__ float2 s_med[256];   // per pixel: bits(median_c), dL_dmedian
 
@@ -416,6 +415,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
         // every passing entry below last_contributor was blended), so this mask is exact: entries and
         // quadrants without contribution are never touched.
         uint32_t qmask = 0;
+        uint32_t slot_l = 0;  // gradient-record slot of the entry this lane stages: taken with one v_readlane per entry
         bool nolp_l = false;
         if (lane < m) {
             const uint32_t pos_l = (uint32_t)(hi - 1 - lane);
@@ -433,7 +433,7 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
 #pragma unroll
             for (int i = 0; i < BLEND_QUADS; i++) s_rec[i][lane] = rq[i];
             // (the rect's origin word sits in q7.w, in the 64-byte line q4 was just read from)
-            s_slot[lane] = __float_as_uint(q0.z) + instance_number(__float_as_uint(q0.w), __float_as_uint(reinterpret_cast<const float*>(r)[31]),
+            slot_l = __float_as_uint(q0.z) + instance_number(__float_as_uint(q0.w), __float_as_uint(reinterpret_cast<const float*>(r)[31]),
                                                                   (uint32_t)tile_x, (uint32_t)tile_y);
         }
         __syncthreads();
@@ -599,18 +599,28 @@ __device__ __forceinline__ void blend_bwd_tile(const BlendBwdArgs& a) {
             // branch (rare for splats wider than a pixel), so their group is reduced and stored only then.  The record
             // buffer is not cleared: rec_flag[slot] (pre-cleared, one byte) says which parts are valid.
             {
-                const uint32_t slot = s_slot[j];
-                float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
+                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j);
                 float t[16] = {gc0, gc1, gc2, gn0, gn1, gn2, gt0, gt1, gt2, gt3, gt4, gt5, gt6, gt7, gt8, gop};
                 const float y = wave_sum16_to_quads(t, lane_b3, lane_b2);
-                const bool slot_ok = slot < a.n_slots;  // false only in a frame that overflowed its presized capacity
-                if (quad_writer && slot_ok) rec[term_of_lane] = y;  // sixteen lanes, sixteen consecutive floats
-                const bool lp = __ballot(lowpass != 0.0f) != 0ull;
-                if (lp) {
-                    const float r4 = wave_sum4_to_rows(glp0, glp1, 0.0f, 0.0f);
-                    if (row_writer && slot_ok) rec[16 + row] = r4;
+                // ONE uniform branch around the stores (false only in a frame that overflowed its presized capacity) instead of
+                // the test ANDed into each store's lane mask; and the validity byte goes out with the sixteen terms, from the
+                // same sixteen lanes (one address, one value), not from lane 0 in an EXEC region of its own
+                if (slot < a.n_slots) {
+                    float* rec = a.grad_inst + (size_t)slot * GRAD_STRIDE;
+                    // the validity byte as a word in an SGPR, by hand: 1, or 3 when some pixel took the low-pass branch (as a
+                    // bool hipcc makes two lane masks of it and selects the byte from one of them inside the store's region)
+                    const uint64_t lp_lanes = __ballot(lowpass != 0.0f);
+                    uint32_t valid;
+                    asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 3, 1" : "=s"(valid) : "s"(lp_lanes) : "scc");
+                    if (quad_writer) {
+                        rec[term_of_lane] = y;  // sixteen lanes, sixteen consecutive floats
+                        a.rec_flag[slot] = (uint8_t)valid;
+                    }
+                    if (valid & 2u) {
+                        const float r4 = wave_sum4_to_rows(glp0, glp1, 0.0f, 0.0f);
+                        if (row_writer) rec[16 + row] = r4;
+                    }
                 }
-                if (lane == 0 && slot_ok) a.rec_flag[slot] = lp ? 3 : 1;
             }
         }
     }
