@@ -17,7 +17,7 @@ python bench.py --scaling strong --no-cpu-baseline > gpurun_out/r06/bench_s3_str
 python tools/affine_stats.py s1 s2 s3 s5 2>&1 | grep -v amdgpu.ids > gpurun_out/r06/affine_share.txt
 # distCUDA2: per-kernel times under rocprofv3 (kernel trace + stats only)
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_knn && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_knn -- python $REPO/tools/knn_bench.py $REPO/g4splat_amd/libg4s_hip.so > /tmp/prof_knn.log 2>&1; find /tmp/prof_knn -name "*kernel_stats.csv" -exec cp {} $REPO/gpurun_out/r06/knn_kernel_stats.csv \; ; grep -v amdgpu.ids /tmp/prof_knn.log > $REPO/gpurun_out/r06/knn_under_rocprof.txt )
-python tools/knn_bench.py g4splat_amd/libg4s_hip.so var/knn_r05.so 2>&1 | grep -v amdgpu.ids > gpurun_out/r06/knn_bench.txt
+python tools/knn_bench.py g4splat_amd/libg4s_hip.so 2>&1 | grep -v amdgpu.ids > gpurun_out/r06/knn_bench.txt
 python tools/micro/sparse_gather_local_cost.py 8 2>&1 | grep -v amdgpu.ids > gpurun_out/r06/sparse_gather_local_cost.txt
 python tools/micro/sparse_gather_local_cost.py 2 0.39 2>&1 | grep -v amdgpu.ids >> gpurun_out/r06/sparse_gather_local_cost.txt
 python tools/micro/owner_local_cost.py 8 2>&1 | grep -v amdgpu.ids > gpurun_out/r06/owner_local_cost.txt
