@@ -949,20 +949,13 @@ __device__ __forceinline__ void fold_block(const PreprocessBwdArgs& a, const Fol
 // dL_dopacity, dL_dscale, dL_drot, dL_dsh -- are ADDED to what their tensors hold; blocks without a visible Gaussian
 // touch none of them and nothing is zero-filled.  The per-view outputs (dL_dmean2D, dL_dcolor, dL_dnormal,
 // dL_dtransMat) are written as always.
-#ifndef G4S_K8_WAVES
-#define G4S_K8_WAVES 4
-#endif
 template <int SH_MODE, bool ACC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(G4S_K8_WAVES, G4S_K8_WAVES))) preprocess_bwd_kernel(PreprocessBwdArgs a, FoldShZero z0, FoldShZero z1) {
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a, FoldShZero z0, FoldShZero z1) {
     // one LDS buffer, used twice: the folded terms (256 x 19 floats) of phase 1, then the block's 256 x 28 output floats
     // on their way to coalesced 16-byte stores (K8_OUT_* below)
     __shared__ float s_buf[256 * K8_OUT_FLOATS];
     float* s_sum = s_buf;
-    // (offsets and counts of the block's record runs: only the fold reads them -- they sit behind its 256 x 19 sums in the
-    // same buffer, and the workgroup stays under 32 KB of LDS: five of them per CU)
-    static_assert(256 * K8_SUM_STRIDE + 512 <= 256 * K8_OUT_FLOATS, "the fold's sums and run tables share s_buf");
-    uint32_t* s_off = reinterpret_cast<uint32_t*>(s_buf + 256 * K8_SUM_STRIDE);
-    uint32_t* s_cnt = s_off + 256;
+    __shared__ uint32_t s_off[256], s_cnt[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_vis[256];  // (read back sixteen bytes at a time for the packed rows)
     const int t = (int)threadIdx.x;
     const int idx = (int)(blockIdx.x * 256 + t);
